@@ -1,0 +1,177 @@
+"""ctypes front end of the C oracle (oracle/crd_oracle.c).  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this module; the product
+(crdmodel_amd/, libcrd.so) never does.  PARITY UNPINNED against reference-run output -- see crd_oracle.h.
+
+State vectors cross this interface in the reference's own layout: AoS [u, v] pairs, theta (i) fastest,
+IDX(i, j) = 2 i + 2 j nxl (/root/reference/src/FHNmodel_torus.cpp:60), i.e. numpy shape (nyl, nxl, 2).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libcrd_oracle.so")
+
+FHN, GOLDBETER = 0, 1
+TORUS, FLAT = 0, 1
+
+
+class Problem(C.Structure):
+    """Mirror of crd_oracle_problem."""
+
+    _fields_ = [
+        ("model", C.c_int), ("surface", C.c_int),
+        ("nx", C.c_long), ("ny", C.c_long),
+        ("is_", C.c_long), ("ie", C.c_long), ("js", C.c_long), ("je", C.c_long),
+        ("dx", C.c_double), ("dy", C.c_double),
+        ("xmin", C.c_double), ("xmax", C.c_double), ("ymin", C.c_double), ("ymax", C.c_double),
+        ("R", C.c_double), ("r", C.c_double),
+        ("diff", C.c_double),
+        ("beta", C.c_double), ("beta_min", C.c_double), ("beta_max", C.c_double),
+        ("vary_beta", C.c_int), ("just_diffusion", C.c_int),
+        ("t_boundary", C.c_double),
+    ]
+
+    @property
+    def nxl(self):
+        return self.ie - self.is_ + 1
+
+    @property
+    def nyl(self):
+        return self.je - self.js + 1
+
+
+class IC(C.Structure):
+    _fields_ = [("wave_length", C.c_double), ("wave_width", C.c_double), ("wave_inside", C.c_int),
+                ("ic_type", C.c_int), ("s0", C.c_double), ("s1", C.c_double)]
+
+
+def build(force=False):
+    """Compile the oracle with the committed Makefile (gcc only; seconds)."""
+    src = [os.path.join(_HERE, f) for f in ("crd_oracle.c", "crd_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_LIB_PATH)
+            and all(os.path.getmtime(_LIB_PATH) >= os.path.getmtime(s) for s in src)):
+        return _LIB_PATH
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_LIB_PATH)
+        dp = C.POINTER(C.c_double)
+        lp = C.POINTER(C.c_long)
+        L.crd_oracle_geometry.argtypes = [C.c_int, C.c_double, C.c_double, C.c_long, C.c_long, C.POINTER(Problem)]
+        L.crd_oracle_decomp.argtypes = [C.c_long, C.c_long, C.c_int, C.c_int, C.c_int, C.c_int, lp, lp, lp, lp]
+        L.crd_oracle_decomp.restype = None
+        L.crd_oracle_fhn_steady.argtypes = [C.c_double, dp, dp]
+        L.crd_oracle_fhn_steady.restype = None
+        L.crd_oracle_goldbeter_steady.argtypes = [C.c_double, dp, dp]
+        L.crd_oracle_initial_conditions.argtypes = [C.POINTER(Problem), C.POINTER(IC), dp]
+        L.crd_oracle_rhs_subdomain.argtypes = [C.POINTER(Problem), C.c_double, dp, dp, dp, dp, dp, dp, C.c_int]
+        L.crd_oracle_pack_edges.argtypes = [C.POINTER(Problem), dp, dp, dp, dp, dp]
+        L.crd_oracle_pack_edges.restype = None
+        L.crd_oracle_rhs_global.argtypes = [C.POINTER(Problem), C.c_double, dp, dp, C.c_int, C.c_int, C.c_int]
+        L.crd_oracle_rk4.argtypes = [C.POINTER(Problem), dp, C.c_double, C.c_double, C.c_long, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _dp(a):
+    assert a.dtype == np.float64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def make_problem(model, surface, nx, surface_length, surface_width, diffusion, beta, *, ny=0, beta_min=0.0,
+                 beta_max=0.0, vary_beta=0, just_diffusion=0, t_boundary=0.0):
+    """Whole-domain problem; ny=0 derives ny the reference's way, ny>0 is the phiMesh override."""
+    p = Problem()
+    rc = lib().crd_oracle_geometry(surface, surface_length, surface_width, nx, ny, C.byref(p))
+    if rc != 0:
+        raise ValueError("crd_oracle_geometry failed")
+    p.model = model
+    p.diff = diffusion
+    p.beta, p.beta_min, p.beta_max = beta, beta_min, beta_max
+    p.vary_beta, p.just_diffusion = vary_beta, just_diffusion
+    p.t_boundary = t_boundary
+    return p
+
+
+def subproblem(p, d0, d1, c0, c1):
+    """Copy of p restricted to block (c0, c1) of a d0 x d1 process grid."""
+    q = Problem.from_buffer_copy(p)
+    is_, ie, js, je = C.c_long(), C.c_long(), C.c_long(), C.c_long()
+    lib().crd_oracle_decomp(p.nx, p.ny, d0, d1, c0, c1, C.byref(is_), C.byref(ie), C.byref(js), C.byref(je))
+    q.is_, q.ie, q.js, q.je = is_.value, ie.value, js.value, je.value
+    return q
+
+
+def fhn_steady(beta):
+    a, b = C.c_double(), C.c_double()
+    lib().crd_oracle_fhn_steady(beta, C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+def goldbeter_steady(beta):
+    a, b = C.c_double(), C.c_double()
+    if lib().crd_oracle_goldbeter_steady(beta, C.byref(a), C.byref(b)) != 0:
+        raise ValueError("no Goldbeter steady state")
+    return a.value, b.value
+
+
+def steady(model, beta):
+    return fhn_steady(beta) if model == FHN else goldbeter_steady(beta)
+
+
+def initial_conditions(p, wave_length, wave_width, wave_inside=0, ic_type=0, steady_state=None):
+    s0, s1 = steady_state if steady_state is not None else steady(p.model, p.beta)
+    ic = IC(wave_length, wave_width, wave_inside, ic_type, s0, s1)
+    y = np.empty((p.nyl, p.nxl, 2), dtype=np.float64)
+    if lib().crd_oracle_initial_conditions(C.byref(p), C.byref(ic), _dp(y)) != 0:
+        raise ValueError("crd_oracle_initial_conditions failed")
+    return y
+
+
+def rhs(p, t, y, d0=1, d1=1, nthreads=1):
+    """ydot = f(t, y) on the whole domain through a d0 x d1 block decomposition."""
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    assert y.shape == (p.ny, p.nx, 2)
+    ydot = np.empty_like(y)
+    if lib().crd_oracle_rhs_global(C.byref(p), t, _dp(y), _dp(ydot), d0, d1, nthreads) != 0:
+        raise RuntimeError("crd_oracle_rhs_global failed")
+    return ydot
+
+
+def rhs_subdomain(p, t, y, wrecv, erecv, srecv, nrecv, nthreads=1):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    assert y.shape == (p.nyl, p.nxl, 2)
+    ydot = np.empty_like(y)
+    strips = [np.ascontiguousarray(s, dtype=np.float64) for s in (wrecv, erecv, srecv, nrecv)]
+    if lib().crd_oracle_rhs_subdomain(C.byref(p), t, _dp(y), _dp(ydot), *[_dp(s) for s in strips], nthreads) != 0:
+        raise RuntimeError("crd_oracle_rhs_subdomain failed")
+    return ydot
+
+
+def pack_edges(p, y):
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    w, e = np.empty(2 * p.nyl), np.empty(2 * p.nyl)
+    s, n = np.empty(2 * p.nxl), np.empty(2 * p.nxl)
+    lib().crd_oracle_pack_edges(C.byref(p), _dp(y), _dp(w), _dp(e), _dp(s), _dp(n))
+    return w, e, s, n
+
+
+def rk4(p, y, t0, dt, nsteps, nthreads=1):
+    """Returns y advanced by nsteps classical RK4 steps (input untouched)."""
+    out = np.array(y, dtype=np.float64, order="C", copy=True)
+    assert out.shape == (p.ny, p.nx, 2)
+    if lib().crd_oracle_rk4(C.byref(p), _dp(out), t0, dt, nsteps, nthreads) != 0:
+        raise RuntimeError("crd_oracle_rk4 failed")
+    return out
