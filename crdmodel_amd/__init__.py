@@ -1,0 +1,8 @@
+"""crdmodel_amd -- MI355X-native RHS / RK4 path of CRDModel behind a C ABI (include/crd.h).
+
+`crdmodel_amd/csrc` holds the hand-written HIP kernels and the C++ host library (libcrd.so, built in-tree);
+`crdmodel_amd.solver` mirrors the reference's interface for this path on top of that ABI via ctypes.
+"""
+from . import _capi  # noqa: F401
+from .solver import (LocalGroup, Slab, Writer, grid_of, initial_conditions, load_ini, make_params, rccl_unique_id,  # noqa: F401
+                     run_config, slab_extents, stable_dt, steady_state)

@@ -1,0 +1,132 @@
+"""ctypes declarations of the libcrd C ABI (include/crd.h).  Thin: every call goes straight to the HIP library.
+
+There is no Python or CPU fallback: if libcrd.so is missing or cannot be loaded, importing this module's `lib()`
+raises, and any device call without a GPU returns CRD_EHIP which `check()` turns into an exception.
+"""
+import ctypes as C
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcrd.so")
+
+OK, EINVAL, ENOMEM, EHIP, ERCCL, EIO, EPARSE, ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
+MODEL_FHN, MODEL_GOLDBETER = 0, 1
+SURFACE_TORUS, SURFACE_FLAT = 0, 1
+PRECISION_F64, PRECISION_F32 = 0, 1
+STEPPER_AUTO, STEPPER_STAGED, STEPPER_FUSED = 0, 1, 2
+
+MODELS = {"fhn": MODEL_FHN, "goldbeter": MODEL_GOLDBETER}
+SURFACES = {"torus": SURFACE_TORUS, "flat": SURFACE_FLAT}
+STEPPERS = {"auto": STEPPER_AUTO, "staged": STEPPER_STAGED, "fused": STEPPER_FUSED}
+
+
+class Params(C.Structure):
+    """crd_params"""
+
+    _fields_ = [
+        ("model", C.c_int32), ("surface", C.c_int32),
+        ("nx", C.c_int64), ("ny", C.c_int64),
+        ("surface_length", C.c_double), ("surface_width", C.c_double),
+        ("diffusion", C.c_double), ("beta", C.c_double), ("beta_min", C.c_double), ("beta_max", C.c_double),
+        ("vary_beta", C.c_int32), ("just_diffusion", C.c_int32),
+        ("t_boundary", C.c_double),
+        ("precision", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class Grid(C.Structure):
+    """crd_grid"""
+
+    _fields_ = [
+        ("nx", C.c_int64), ("ny", C.c_int64), ("dx", C.c_double), ("dy", C.c_double),
+        ("xmin", C.c_double), ("xmax", C.c_double), ("ymin", C.c_double), ("ymax", C.c_double),
+        ("R", C.c_double), ("r", C.c_double),
+    ]
+
+
+class RunConfig(C.Structure):
+    """crd_run_config"""
+
+    _fields_ = [
+        ("params", Params),
+        ("wave_length", C.c_double), ("wave_width", C.c_double),
+        ("wave_inside", C.c_int32), ("output_timestep", C.c_int32),
+        ("t_final", C.c_double),
+        ("include_all_vars", C.c_int32), ("ic_type", C.c_int32),
+        ("dt", C.c_double), ("dt_safety", C.c_double),
+        ("n_gpus", C.c_int32), ("stepper", C.c_int32),
+    ]
+
+
+# name -> (restype, argtypes); the test suite checks this table against include/crd.h symbol by symbol.
+_vp = C.c_void_p
+_SIGNATURES = {
+    "crd_abi_version": (C.c_int, []),
+    "crd_status_string": (C.c_char_p, [C.c_int]),
+    "crd_config_load_ini": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(RunConfig), C.c_char_p, C.c_size_t]),
+    "crd_grid_from_params": (C.c_int, [C.POINTER(Params), C.POINTER(Grid)]),
+    "crd_slab_extents": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "crd_steady_state": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "crd_initial_conditions": (C.c_int, [C.POINTER(RunConfig), C.c_int64, C.c_int64, _vp]),
+    "crd_stable_dt": (C.c_double, [C.POINTER(Params)]),
+    "crd_writer_open": (C.c_int, [C.POINTER(RunConfig), C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "crd_writer_write_row": (C.c_int, [_vp, _vp]),
+    "crd_writer_close": (C.c_int, [_vp]),
+    "crd_create": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "crd_destroy": (None, [_vp]),
+    "crd_last_error": (C.c_char_p, [_vp]),
+    "crd_get_grid": (C.c_int, [_vp, C.POINTER(Grid)]),
+    "crd_get_slab": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "crd_comm_attach_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "crd_comm_unique_id": (C.c_int, [_vp]),
+    "crd_comm_init_rccl": (C.c_int, [_vp, _vp]),
+    "crd_state_upload": (C.c_int, [_vp, _vp, C.c_int]),
+    "crd_state_download": (C.c_int, [_vp, _vp, C.c_int]),
+    "crd_rhs_host": (C.c_int, [_vp, C.c_double, _vp, _vp]),
+    "crd_rhs_device": (C.c_int, [_vp, C.c_double, _vp, _vp]),
+    "crd_set_stepper": (C.c_int, [_vp, C.c_int]),
+    "crd_step_rk4": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int64]),
+    "crd_synchronize": (C.c_int, [_vp]),
+    "crd_group_step_rk4": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.c_double, C.c_int64]),
+    "crd_group_rhs_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
+    "crd_step_rk4_timed": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int64, C.POINTER(C.c_double),
+                                     C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "crd_dominant_kernel_name": (C.c_char_p, [_vp]),
+    "crd_state_max_abs": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+}
+
+_lib = None
+
+
+class CrdError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = "%s failed: %s (%d)" % (where, lib().crd_status_string(status).decode(), status)
+        if detail:
+            msg += ": " + detail
+        super().__init__(msg)
+
+
+def lib():
+    """Load libcrd.so (built in-tree by crdmodel_amd.build / `make -C crdmodel_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                "libcrd.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C crdmodel_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(L, name)  # AttributeError here = header / library mismatch
+            fn.restype = res
+            fn.argtypes = args
+        if L.crd_abi_version() != 1:
+            raise ImportError("libcrd.so ABI version mismatch")
+        _lib = L
+    return _lib
+
+
+def check(status, where, ctx=None):
+    if status != OK:
+        detail = lib().crd_last_error(ctx).decode() if ctx is not None or status in (EHIP, ERCCL, EINVAL, ENOMEM) else ""
+        raise CrdError(status, where, detail)

@@ -1,0 +1,41 @@
+// crd_internal.h -- declarations shared by the translation units of libcrd (not part of the ABI).
+#pragma once
+
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "crd.h"
+
+namespace crd {
+
+// Constants of the reference programs.
+constexpr double kPi = 3.1415926535897932;  // src/FHNmodel_torus.cpp:63
+constexpr double kFhnEpsilon = 0.36;        // src/FHNmodel_torus.cpp:68
+// src/GoldbeterModel_torus.cpp:67-78
+constexpr double kGbV0 = 1.0, kGbK = 10.0, kGbKf = 1.0, kGbV1 = 7.3, kGbVm2 = 65.0, kGbVm3 = 500.0;
+constexpr double kGbK2 = 1.0, kGbKr = 2.0, kGbKa = 0.9;
+
+// Number of ghost rows kept above and below every slab plane (the fused stepper consumes four per step).
+constexpr int kGhost = 4;
+
+// Host-side coefficient tables of the diffusion operator written as
+//   du = cA[i] (uE - uW) + cX (uE - 2 uC + uW) + cP[i] (uN - 2 uC + uS)
+// (torus: src/FHNmodel_torus.cpp:535-537; flat: cA = 0, cX = D/dx^2, cP = D/dy^2, src/FHNmodel_flat.cpp:489-491).
+struct Coefficients {
+	std::vector<double> cA;  // nx
+	std::vector<double> cP;  // nx
+	double cX = 0.0;
+};
+void build_coefficients(const crd_params &p, const crd_grid &g, Coefficients *out);
+
+// b(j) of src/FHNmodel_torus.cpp:623-632 for global rows [j0, j1).
+void build_beta_rows(const crd_params &p, const crd_grid &g, int64_t j0, int64_t j1, std::vector<double> *out);
+
+bool validate_params(const crd_params &p, std::string *why);
+
+const char *model_name(int model);      // "FHNmodel" / "GoldbeterModel"
+const char *surface_name(int surface);  // "torus" / "flat"
+const char *var_name(int model, int var);
+
+}  // namespace crd

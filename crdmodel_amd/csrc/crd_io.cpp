@@ -1,0 +1,318 @@
+// crd_io.cpp -- the two file formats libcrd shares with the reference: the .ini parameter file it reads and the
+// per-subdomain text files it writes (consumed unmodified by util/*/plot_*.py and MapOutputToTorus.py).
+#include <cerrno>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+
+#include "crd_internal.h"
+
+namespace {
+
+std::string trim(const std::string &s)
+{
+	size_t a = 0, b = s.size();
+	while (a < b && std::isspace((unsigned char)s[a])) a++;
+	while (b > a && std::isspace((unsigned char)s[b - 1])) b--;
+	return s.substr(a, b - a);
+}
+
+// Minimal INI reader with the rules of boost::property_tree::ini_parser that the shipped files rely on
+// (data/FHNmodelArgs.ini:1-20): '#' or ';' starts a comment line, "[Section]", "key = value" with both sides
+// trimmed (the shipped values carry trailing tabs), duplicate keys and lines without '=' are errors.
+struct Ini {
+	std::map<std::string, std::string> kv;  // "Section.key" -> value
+
+	bool load(const char *path, std::string *err)
+	{
+		std::ifstream in(path);
+		if (!in) {
+			*err = std::string("cannot open ") + path;
+			return false;
+		}
+		std::string line, section;
+		int lineno = 0;
+		while (std::getline(in, line)) {
+			lineno++;
+			line = trim(line);
+			if (line.empty() || line[0] == '#' || line[0] == ';') continue;
+			if (line[0] == '[') {
+				if (line.back() != ']') {
+					*err = "unmatched '[' at line " + std::to_string(lineno);
+					return false;
+				}
+				section = trim(line.substr(1, line.size() - 2));
+				continue;
+			}
+			const size_t eq = line.find('=');
+			if (eq == std::string::npos) {
+				*err = "'=' character not found at line " + std::to_string(lineno);
+				return false;
+			}
+			const std::string key = trim(line.substr(0, eq));
+			if (key.empty()) {
+				*err = "key expected at line " + std::to_string(lineno);
+				return false;
+			}
+			const std::string full = section.empty() ? key : section + "." + key;
+			if (kv.count(full)) {
+				*err = "duplicate key name '" + full + "' at line " + std::to_string(lineno);
+				return false;
+			}
+			kv[full] = trim(line.substr(eq + 1));
+		}
+		return true;
+	}
+
+	bool has(const std::string &k) const { return kv.count(k) != 0; }
+
+	// pt.get<T>(): the whole value must convert (boost's stream_translator rejects trailing characters).
+	bool get_double(const std::string &k, double *out, std::string *err) const
+	{
+		auto it = kv.find(k);
+		if (it == kv.end()) {
+			*err = "No such node (" + k + ")";
+			return false;
+		}
+		std::istringstream iss(it->second);
+		iss >> *out;
+		if (iss.fail()) {
+			*err = "conversion of data to type \"double\" failed (" + k + " = " + it->second + ")";
+			return false;
+		}
+		if (!iss.eof()) iss >> std::ws;
+		if (!iss.eof()) {
+			*err = "conversion of data to type \"double\" failed (" + k + " = " + it->second + ")";
+			return false;
+		}
+		return true;
+	}
+
+	bool get_int(const std::string &k, long long *out, std::string *err) const
+	{
+		auto it = kv.find(k);
+		if (it == kv.end()) {
+			*err = "No such node (" + k + ")";
+			return false;
+		}
+		std::istringstream iss(it->second);
+		iss >> *out;
+		if (!iss.fail() && !iss.eof()) iss >> std::ws;
+		if (iss.fail() || !iss.eof()) {
+			*err = "conversion of data to type \"int\" failed (" + k + " = " + it->second + ")";
+			return false;
+		}
+		return true;
+	}
+};
+
+void set_err(char *err, size_t len, const std::string &msg)
+{
+	if (err && len) {
+		std::snprintf(err, len, "%s", msg.c_str());
+	}
+}
+
+}  // namespace
+
+extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd_run_config *cfg, char *err, size_t err_len)
+{
+	if (!path || !cfg) return CRD_EINVAL;
+	if ((model != CRD_MODEL_FHN && model != CRD_MODEL_GOLDBETER) || (surface != CRD_SURFACE_TORUS && surface != CRD_SURFACE_FLAT)) {
+		set_err(err, err_len, "bad model / surface");
+		return CRD_EINVAL;
+	}
+	Ini ini;
+	std::string why;
+	if (!ini.load(path, &why)) {
+		set_err(err, err_len, why);
+		return why.rfind("cannot open", 0) == 0 ? CRD_EIO : CRD_EPARSE;
+	}
+	std::memset(cfg, 0, sizeof(*cfg));
+	crd_params &p = cfg->params;
+	p.model = model;
+	p.surface = surface;
+	p.precision = CRD_PRECISION_F64;
+	cfg->dt_safety = 0.8;
+	cfg->n_gpus = 1;
+	cfg->stepper = CRD_STEPPER_AUTO;
+
+	bool ok = true;
+	auto D = [&](const char *k, double *dst) { ok = ok && ini.get_double(std::string("Parameters.") + k, dst, &why); };
+	long long iv = 0;
+	auto I = [&](const std::string &k, int32_t *dst) {
+		if (ok && (ok = ini.get_int(k, &iv, &why))) *dst = (int32_t)iv;
+	};
+
+	// Keys every program reads: src/FHNmodel_torus.cpp:160-169 and siblings.
+	D("diffusion", &p.diffusion);
+	D("beta", &p.beta);
+	D("surfaceLength", &p.surface_length);
+	D("surfaceWidth", &p.surface_width);
+	D("waveLength", &cfg->wave_length);
+	D("waveWidth", &cfg->wave_width);
+	I("Parameters.outputTimestep", &cfg->output_timestep);
+	D("tBoundary", &p.t_boundary);
+	D("tFinal", &cfg->t_final);
+	if (surface == CRD_SURFACE_TORUS) I("Parameters.waveInside", &cfg->wave_inside);  // torus programs only (:166)
+
+	// Mesh key: FHN reads thetaMesh (src/FHNmodel_torus.cpp:170), Goldbeter xMesh (src/GoldbeterModel_torus.cpp:184);
+	// the shipped data/FHNmodelArgs.ini carries xMesh, data/temp.ini thetaMesh, so either is accepted.
+	if (ok) {
+		const char *own = (model == CRD_MODEL_FHN) ? "Parameters.thetaMesh" : "Parameters.xMesh";
+		const char *other = (model == CRD_MODEL_FHN) ? "Parameters.xMesh" : "Parameters.thetaMesh";
+		const char *use = ini.has(own) ? own : (ini.has(other) ? other : own);
+		if ((ok = ini.get_int(use, &iv, &why))) p.nx = iv;
+	}
+	// phiMesh / yMesh: extension; absent = derive ny like the reference.
+	if (ok) {
+		for (const char *k : {"Parameters.phiMesh", "Parameters.yMesh"}) {
+			if (ini.has(k)) {
+				if ((ok = ini.get_int(k, &iv, &why))) p.ny = iv;
+				break;
+			}
+		}
+	}
+
+	I("System.includeAllVars", &cfg->include_all_vars);
+	I("System.varyBeta", &p.vary_beta);
+
+	// betaMin / betaMax: read by both FHN programs (:171-172) and by Goldbeter flat (src/GoldbeterModel_flat.cpp:179-180);
+	// Goldbeter torus never reads them, its BETA_MIN / BETA_MAX stay 0 (src/GoldbeterModel_torus.cpp:101-102).
+	// Lenient superset: mandatory only when varyBeta = 1 actually uses them.
+	const bool reads_beta_range = !(model == CRD_MODEL_GOLDBETER && surface == CRD_SURFACE_TORUS);
+	if (ok && reads_beta_range) {
+		const bool needed = (p.vary_beta != 0);
+		if (needed || ini.has("Parameters.betaMin")) D("betaMin", &p.beta_min);
+		if (needed || ini.has("Parameters.betaMax")) D("betaMax", &p.beta_max);
+	}
+	if (model == CRD_MODEL_GOLDBETER) {
+		I("System.justDiffusion", &p.just_diffusion);
+		if (surface == CRD_SURFACE_FLAT) I("System.icType", &cfg->ic_type);  // src/GoldbeterModel_flat.cpp:184 only
+	}
+
+	// [Solver] extension section.
+	if (ok && ini.has("Solver.dt")) ok = ini.get_double("Solver.dt", &cfg->dt, &why);
+	if (ok && ini.has("Solver.dtSafety")) ok = ini.get_double("Solver.dtSafety", &cfg->dt_safety, &why);
+	if (ok && ini.has("Solver.gpus")) I("Solver.gpus", &cfg->n_gpus);
+	if (ok && ini.has("Solver.stepper")) I("Solver.stepper", &cfg->stepper);
+	if (ok && ini.has("Solver.precision")) {
+		int32_t bits = 64;
+		I("Solver.precision", &bits);
+		if (ok && bits != 64 && bits != 32) {
+			ok = false;
+			why = "Solver.precision must be 64 or 32";
+		}
+		p.precision = (bits == 32) ? CRD_PRECISION_F32 : CRD_PRECISION_F64;
+	}
+
+	if (!ok) {
+		set_err(err, err_len, why);
+		return CRD_EPARSE;
+	}
+	if (!crd::validate_params(p, &why)) {
+		set_err(err, err_len, why);
+		return CRD_EINVAL;
+	}
+	if (cfg->output_timestep < 1 || !(cfg->t_final > 0.0) || cfg->n_gpus < 1 || !(cfg->dt >= 0.0) || !(cfg->dt_safety > 0.0)) {
+		set_err(err, err_len, "outputTimestep, tFinal, gpus, dt or dtSafety out of range");
+		return CRD_EINVAL;
+	}
+	set_err(err, err_len, "");
+	return CRD_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Text writer.  Header and rows as src/FHNmodel_torus.cpp:376-410,438-455: the subdomain file holds
+// "nx  ny  is  ie  js  je xmin xmax tfinal"; each data row is nyl*nxl values " %.16e" (j outer, i inner) + "\n";
+// the second-variable file is always created but only filled when includeAllVars == 1.
+// ---------------------------------------------------------------------------------------------------------------
+struct crd_writer {
+	FILE *f0 = nullptr;
+	FILE *f1 = nullptr;
+	int64_t nxl = 0, nyl = 0;
+	bool all_vars = false;
+	std::vector<char> line;
+};
+
+namespace {
+
+// One value as printf(" %.16e", v) writes it.
+inline char *put_e16(char *out, double v)
+{
+	int n = std::snprintf(out, 32, " %.16e", v);
+	return out + n;
+}
+
+}  // namespace
+
+extern "C" int crd_writer_open(const crd_run_config *cfg, const char *dir, int slab, int n_slabs, crd_writer **out)
+{
+	if (!cfg || !out) return CRD_EINVAL;
+	*out = nullptr;
+	crd_grid g;
+	int rc = crd_grid_from_params(&cfg->params, &g);
+	if (rc != CRD_OK) return rc;
+	int64_t js, je;
+	rc = crd_slab_extents(g.ny, slab, n_slabs, &js, &je);
+	if (rc != CRD_OK) return rc;
+	if (slab > 999) return CRD_EINVAL;
+
+	const std::string base = std::string(dir && *dir ? dir : ".") + "/" + crd::model_name(cfg->params.model) + "_" +
+	                         crd::surface_name(cfg->params.surface) + "_";
+	char tag[16];
+	std::snprintf(tag, sizeof tag, ".%03i.txt", slab);
+
+	FILE *fs = std::fopen((base + "subdomain" + tag).c_str(), "w");
+	if (!fs) return CRD_EIO;
+	std::fprintf(fs, "%li  %li  %li  %li  %li  %li %f %f %f\n", (long)g.nx, (long)g.ny, 0L, (long)(g.nx - 1), (long)js, (long)je,
+	             g.xmin, g.xmax, cfg->t_final);
+	std::fclose(fs);
+
+	crd_writer *w = new (std::nothrow) crd_writer;
+	if (!w) return CRD_ENOMEM;
+	w->nxl = g.nx;
+	w->nyl = je - js + 1;
+	w->all_vars = (cfg->include_all_vars == 1);
+	w->f0 = std::fopen((base + crd::var_name(cfg->params.model, 0) + tag).c_str(), "w");
+	w->f1 = std::fopen((base + crd::var_name(cfg->params.model, 1) + tag).c_str(), "w");
+	if (!w->f0 || !w->f1) {
+		crd_writer_close(w);
+		return CRD_EIO;
+	}
+	*out = w;
+	return CRD_OK;
+}
+
+extern "C" int crd_writer_write_row(crd_writer *w, const double *y_aos)
+{
+	if (!w || !y_aos || !w->f0) return CRD_EINVAL;
+	const int64_t n = w->nxl * w->nyl;
+	const int64_t chunk = 4096;
+	w->line.resize((size_t)chunk * 32 + 2);
+	for (int var = 0; var < (w->all_vars ? 2 : 1); var++) {
+		FILE *f = var == 0 ? w->f0 : w->f1;
+		for (int64_t q0 = 0; q0 < n; q0 += chunk) {
+			const int64_t q1 = (q0 + chunk < n) ? q0 + chunk : n;
+			char *c = w->line.data();
+			for (int64_t q = q0; q < q1; q++) c = put_e16(c, y_aos[2 * q + var]);
+			if (std::fwrite(w->line.data(), 1, (size_t)(c - w->line.data()), f) != (size_t)(c - w->line.data())) return CRD_EIO;
+		}
+		if (std::fputc('\n', f) == EOF) return CRD_EIO;
+	}
+	return CRD_OK;
+}
+
+extern "C" int crd_writer_close(crd_writer *w)
+{
+	if (!w) return CRD_OK;
+	int rc = CRD_OK;
+	if (w->f0 && std::fclose(w->f0) != 0) rc = CRD_EIO;
+	if (w->f1 && std::fclose(w->f1) != 0) rc = CRD_EIO;
+	delete w;
+	return rc;
+}

@@ -1,0 +1,74 @@
+// crd_kernels.h -- launch interface between the context code (crd_context.cpp) and the HIP kernels
+// (crd_kernels.hip).  Plain structs; every pointer is a device pointer on the context's device.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace crd {
+
+// A field plane on the device: (nyl + 2*kGhost) rows of nx reals, theta fastest; local row j (j in
+// [-kGhost, nyl+kGhost)) starts at base + (j + kGhost) * nx.  Two planes (var0 = diffusing, var1 = local) make a state.
+struct Planes {
+	void *u;
+	void *v;
+};
+
+// Everything a kernel needs to know about the slab; passed by value as a kernel argument.
+struct SlabDesc {
+	const void *cA;    // nx: advection coefficient  D (-sin th / (r rho)) / (2 dx)     (0 for flat)
+	const void *cP;    // nx: phi-diffusion coefficient D / rho^2 / dy^2                 (D/dy^2 for flat)
+	const void *brow;  // nyl + 2*kGhost: b(j) per local row, index j + kGhost
+	double cX;         // theta-diffusion coefficient D / r^2 / dx^2                     (D/dx^2 for flat)
+	double ka4;        // Goldbeter pow(KA, p)
+	int nx;
+	int nyl;
+	int wrap;          // 1: single slab, phi neighbours wrap inside the slab; 0: read ghost rows
+	int has_row0;      // slab owns global row 0      (js == 0)
+	int has_rowN;      // slab owns global row ny-1   (je == ny-1)
+	int model;
+	int just_diffusion;
+};
+
+struct StageCall {
+	int stage;       // 0: RHS only (out = f(yin)); 1..4: fused RK4 stage
+	int absorb;      // t_stage < tBoundary
+	double dt;
+	Planes yin;      // stencil input of this stage
+	Planes y0;       // state at the start of the step (stages 1-3)
+	Planes acc;      // running combination (stages 1-4)
+	Planes yout;     // stage output (next stage's input; stage 4: the new state; stage 0: ydot)
+};
+
+// One evaluation of f on AoS device vectors (the ARKRhsFn boundary): y, ydot are [nyl][nx][2];
+// ghost_lo / ghost_hi hold var0 of rows -1 and nyl (ignored when d.wrap).
+hipError_t launch_rhs_aos(int precision, const SlabDesc &d, int absorb, const void *y, void *ydot, const void *ghost_lo,
+                          const void *ghost_hi, hipStream_t s);
+
+// One RK4 stage (or a bare RHS) on SoA planes, rows [row_begin, row_end) of the slab.
+hipError_t launch_stage(int precision, const SlabDesc &d, const StageCall &c, int row_begin, int row_end, hipStream_t s);
+const char *stage_kernel_name(int precision, int model);
+
+// Whole RK4 step in one launch (all four stages on chip); reads y0 with kGhost ghost rows, writes yout rows
+// [row_begin, row_end).  absorb[k] = t_stage_k < tBoundary for the four stages.
+struct FusedCall {
+	double dt;
+	int absorb[4];
+	Planes y0;
+	Planes yout;
+};
+hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, hipStream_t s);
+const char *fused_kernel_name(int precision, int model);
+bool fused_step_supported(int precision, const SlabDesc &d);
+
+// Layout adaptors between the AoS boundary layout (host precision: f64 or device precision) and SoA planes.
+hipError_t launch_aos_to_planes(int precision, int src_is_f64, const void *aos, Planes dst, int nx, int nyl, hipStream_t s);
+hipError_t launch_planes_to_aos(int precision, int dst_is_f64, Planes src, void *aos, int nx, int nyl, hipStream_t s);
+// Extract var0 of one AoS row into a contiguous row (halo packing for crd_rhs_*).
+hipError_t launch_aos_row_extract(int precision, const void *aos, void *row, int nx, int j, hipStream_t s);
+
+// max |u| over the owned rows, written to *out (device double).
+hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s);
+
+}  // namespace crd

@@ -1,0 +1,445 @@
+// crd_kernels.hip -- hand-written HIP kernels for gfx950 (MI355X, wave64): the RHS of CRDModel's f()
+// (src/FHNmodel_torus.cpp:504-667 and its three siblings) as (a) a bare RHS on the reference's AoS vectors and
+// (b) RK4 stage kernels on SoA planes with the stage update fused into the epilogue.
+//
+// Shape of every kernel here: one thread per grid point, 64(theta) x 4 thread blocks sweeping a 64 x 16 tile;
+// the activator tile plus a one-point halo ring is staged in LDS from coalesced row reads (theta is the contiguous
+// axis, so a wavefront reads one 512-B fp64 row segment); theta wrap is index arithmetic at tile load, phi
+// neighbours of the slab's first / last row come from ghost rows (or wrap inside a single slab); the curvature
+// coefficients are per-column tables in HBM (L2-resident); no MFMA -- there is no contraction in this path.
+#include <hip/hip_runtime.h>
+
+#include "crd_internal.h"
+#include "crd_kernels.h"
+
+namespace crd {
+
+namespace {
+
+constexpr int kTX = 64;             // tile width = one wavefront along theta
+constexpr int kBY = 4;              // waves per block
+constexpr int kRPT = 4;             // rows per thread
+constexpr int kTY = kBY * kRPT;     // tile height
+constexpr int kNumXcd = 8;
+
+template <typename Real> struct Pair;
+template <> struct Pair<double> { using type = double2; };
+template <> struct Pair<float> { using type = float2; };
+
+template <typename Real>
+struct Slab {
+	const Real *cA, *cP, *brow;
+	Real cX, ka4;
+	int nx, nyl, wrap, has_row0, has_rowN, just_diffusion;
+};
+
+template <typename Real>
+Slab<Real> typed(const SlabDesc &d)
+{
+	Slab<Real> s;
+	s.cA = static_cast<const Real *>(d.cA);
+	s.cP = static_cast<const Real *>(d.cP);
+	s.brow = static_cast<const Real *>(d.brow) + kGhost;  // index by local row
+	s.cX = (Real)d.cX;
+	s.ka4 = (Real)d.ka4;
+	s.nx = d.nx;
+	s.nyl = d.nyl;
+	s.wrap = d.wrap;
+	s.has_row0 = d.has_row0;
+	s.has_rowN = d.has_rowN;
+	s.just_diffusion = d.just_diffusion;
+	return s;
+}
+
+// Pointer to local row 0 of a plane (ghost rows sit at negative row offsets).
+template <typename Real>
+inline Real *row0(void *plane, int nx)
+{
+	return plane ? static_cast<Real *>(plane) + (size_t)kGhost * (size_t)nx : nullptr;
+}
+
+// The point function: diffusion + kinetics of one grid point.
+//   diffusion  src/FHNmodel_torus.cpp:535-537 with the theta-only factors folded into cA / cX / cP
+//   FHN        src/FHNmodel_torus.cpp:657,660
+//   Goldbeter  src/GoldbeterModel_torus.cpp:694-695,715-716 (pow(x,2), pow(x,4) as multiplies)
+//   absorbing  src/FHNmodel_torus.cpp:643-653 (zero = row is a global phi boundary row and t < TBOUNDARY)
+template <typename Real, int MODEL>
+__device__ __forceinline__ void rhs_point(Real uC, Real uW, Real uE, Real uS, Real uN, Real v, Real cA, Real cX, Real cP, Real b,
+                                          Real ka4, bool zero, bool just_diffusion, Real &du, Real &dv)
+{
+	const Real two = (Real)2;
+	const Real diff = cA * (uE - uW) + cX * ((uE - two * uC) + uW) + cP * ((uN - two * uC) + uS);
+	if (MODEL == CRD_MODEL_FHN) {
+		du = diff + (((Real)3.0 * uC - (uC * uC * uC)) - v);
+		dv = (Real)kFhnEpsilon * (uC + b);
+	} else {
+		const Real z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
+		const Real v2 = (Real)kGbVm2 * z2 / ((Real)(kGbK2 * kGbK2) + z2);
+		const Real v3 = (Real)kGbVm3 * y2 * z4 / (((Real)(kGbKr * kGbKr) + y2) * (ka4 + z4));
+		du = diff + ((((((Real)kGbV0 + (Real)kGbV1 * b) - v2) + v3) + (Real)kGbKf * v) - (Real)kGbK * uC);
+		dv = (v2 - v3) - (Real)kGbKf * v;
+		if (just_diffusion) {  // src/GoldbeterModel_torus.cpp:668: the whole reaction block, absorbing rows included, is skipped
+			du = diff;
+			dv = (Real)0;
+			zero = false;
+		}
+	}
+	if (zero) {
+		du = (Real)0;
+		dv = (Real)0;
+	}
+}
+
+// blockIdx -> tile id.  Workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so tile ids that
+// are consecutive in phi would land on eight different L2s and every halo row would be fetched twice from beyond
+// L2.  This bijection hands each XCD one contiguous run of tiles instead.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks)
+{
+	const int q = nblocks / kNumXcd, rem = nblocks - q * kNumXcd;
+	const int x = bid % kNumXcd, l = bid / kNumXcd;
+	return x * q + (x < rem ? x : rem) + l;
+}
+
+template <typename Real>
+__device__ __forceinline__ int wrap_row(const Slab<Real> &s, int j)
+{
+	if (s.wrap) {
+		if (j < 0) j += s.nyl;
+		else if (j >= s.nyl) j -= s.nyl;
+	}
+	return j;
+}
+
+template <typename Real>
+struct StageArgs {
+	const Real *in_u, *in_v;    // stage input, pointers to local row 0
+	const Real *y0_u, *y0_v;    // step-start state
+	Real *acc_u, *acc_v;        // running combination
+	Real *out_u, *out_v;        // stage output
+	Real h_out, h_acc;          // yout = y0 + h_out k ; acc (+)= h_acc k
+	int absorb;
+};
+
+// RK4 stage kernel on SoA planes.  STAGE 0 writes k = f(yin); stages 1-4 follow SURVEY 8(d)'s scheme:
+//   1: y1 = y0 + dt/2 k1, acc  = y0 + dt/6 k1      2: y2 = y0 + dt/2 k2, acc += dt/3 k2
+//   3: y3 = y0 + dt k3,   acc += dt/3 k3           4: y  = acc + dt/6 k4
+// i.e. 6 + 10 + 10 + 6 = 32 reals of HBM traffic per grid-point-step.
+template <typename Real, int MODEL, int STAGE>
+__global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, StageArgs<Real> a, int row_begin, int row_end, int nbx, int nblocks)
+{
+	__shared__ Real tile[kTY + 2][kTX + 2];
+
+	const int tid = xcd_remap((int)blockIdx.x, nblocks);
+	const int by = tid / nbx, bx = tid - by * nbx;
+	const int tx = threadIdx.x, ty = threadIdx.y;
+	const int nx = s.nx;
+	const int i0 = bx * kTX, i = i0 + tx;
+	const int j0 = row_begin + by * kTY;
+	const bool col_ok = i < nx;
+	const int iw = (i0 == 0) ? nx - 1 : i0 - 1;          // theta wrap: column -1 is column nx-1 (Appendix A.3)
+	const bool last_col = col_ok && (tx == kTX - 1 || i == nx - 1);
+	const int ie = (i == nx - 1) ? 0 : i + 1;
+
+	Real uC[kRPT], vC[kRPT], p0u[kRPT], p0v[kRPT], pau[kRPT], pav[kRPT];
+
+	// Own rows: one coalesced row read per wave, value kept in a register and mirrored into LDS for the neighbours.
+#pragma unroll
+	for (int r = 0; r < kRPT; r++) {
+		const int j = j0 + ty + kBY * r;
+		uC[r] = vC[r] = p0u[r] = p0v[r] = pau[r] = pav[r] = (Real)0;
+		if (j < row_end && col_ok) {
+			const size_t off = (size_t)j * nx;
+			const Real *row = a.in_u + off;
+			uC[r] = row[i];
+			vC[r] = a.in_v[off + i];
+			if (tx == 0) tile[ty + kBY * r + 1][0] = row[iw];
+			if (last_col) tile[ty + kBY * r + 1][tx + 2] = row[ie];
+			if (STAGE == 2 || STAGE == 3) {
+				p0u[r] = a.y0_u[off + i];
+				p0v[r] = a.y0_v[off + i];
+			}
+			if (STAGE >= 2) {
+				pau[r] = a.acc_u[off + i];
+				pav[r] = a.acc_v[off + i];
+			}
+		}
+		if (j < row_end) tile[ty + kBY * r + 1][tx + 1] = uC[r];  // rows past the range belong to the halo loader below
+	}
+	// Halo rows j0-1 (wave 0) and min(j0+kTY, row_end) (wave 1): ghost rows of the slab, or the wrapped row.
+	if (ty < 2 && col_ok) {
+		const int jt = (ty == 0) ? j0 - 1 : ((j0 + kTY < row_end) ? j0 + kTY : row_end);
+		const int tr = (ty == 0) ? 0 : jt - j0 + 1;
+		const Real *row = a.in_u + (ptrdiff_t)wrap_row(s, jt) * nx;
+		tile[tr][tx + 1] = row[i];
+	}
+	const Real cA = col_ok ? s.cA[i] : (Real)0;
+	const Real cP = col_ok ? s.cP[i] : (Real)0;
+	__syncthreads();
+
+#pragma unroll
+	for (int r = 0; r < kRPT; r++) {
+		const int j = j0 + ty + kBY * r;
+		if (!(j < row_end && col_ok)) continue;
+		const int tr = ty + kBY * r + 1;
+		const bool zero = a.absorb && ((s.has_row0 && j == 0) || (s.has_rowN && j == s.nyl - 1));
+		Real du, dv;
+		rhs_point<Real, MODEL>(uC[r], tile[tr][tx], tile[tr][tx + 2], tile[tr - 1][tx + 1], tile[tr + 1][tx + 1], vC[r], cA, s.cX, cP,
+		                       s.brow[j], s.ka4, zero, s.just_diffusion != 0, du, dv);
+		const size_t o = (size_t)j * nx + i;
+		if (STAGE == 0) {
+			a.out_u[o] = du;
+			a.out_v[o] = dv;
+		} else if (STAGE == 1) {
+			a.out_u[o] = uC[r] + a.h_out * du;
+			a.out_v[o] = vC[r] + a.h_out * dv;
+			a.acc_u[o] = uC[r] + a.h_acc * du;
+			a.acc_v[o] = vC[r] + a.h_acc * dv;
+		} else if (STAGE == 2 || STAGE == 3) {
+			a.out_u[o] = p0u[r] + a.h_out * du;
+			a.out_v[o] = p0v[r] + a.h_out * dv;
+			a.acc_u[o] = pau[r] + a.h_acc * du;
+			a.acc_v[o] = pav[r] + a.h_acc * dv;
+		} else {
+			a.out_u[o] = pau[r] + a.h_acc * du;
+			a.out_v[o] = pav[r] + a.h_acc * dv;
+		}
+	}
+}
+
+// Bare RHS on the reference's AoS vectors: y[j][i] = (var0, var1) pairs, one 16-B (fp64) load per point.
+template <typename Real, int MODEL>
+__global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, const typename Pair<Real>::type *__restrict__ y,
+                                                               typename Pair<Real>::type *__restrict__ ydot, const Real *__restrict__ ghost_lo,
+                                                               const Real *__restrict__ ghost_hi, int absorb, int nbx, int nblocks)
+{
+	using P = typename Pair<Real>::type;
+	__shared__ Real tile[kTY + 2][kTX + 2];
+
+	const int tid = xcd_remap((int)blockIdx.x, nblocks);
+	const int by = tid / nbx, bx = tid - by * nbx;
+	const int tx = threadIdx.x, ty = threadIdx.y;
+	const int nx = s.nx, nyl = s.nyl;
+	const int i0 = bx * kTX, i = i0 + tx;
+	const int j0 = by * kTY;
+	const bool col_ok = i < nx;
+	const int iw = (i0 == 0) ? nx - 1 : i0 - 1;
+	const bool last_col = col_ok && (tx == kTX - 1 || i == nx - 1);
+	const int ie = (i == nx - 1) ? 0 : i + 1;
+
+	P own[kRPT];
+#pragma unroll
+	for (int r = 0; r < kRPT; r++) {
+		const int j = j0 + ty + kBY * r;
+		own[r].x = own[r].y = (Real)0;
+		if (j < nyl && col_ok) {
+			const P *row = y + (size_t)j * nx;
+			own[r] = row[i];
+			if (tx == 0) tile[ty + kBY * r + 1][0] = row[iw].x;
+			if (last_col) tile[ty + kBY * r + 1][tx + 2] = row[ie].x;
+		}
+		if (j < nyl) tile[ty + kBY * r + 1][tx + 1] = own[r].x;
+	}
+	if (ty < 2 && col_ok) {
+		const int jt = (ty == 0) ? j0 - 1 : ((j0 + kTY < nyl) ? j0 + kTY : nyl);
+		const int tr = (ty == 0) ? 0 : jt - j0 + 1;
+		Real val;
+		if (jt >= 0 && jt < nyl) val = y[(size_t)jt * nx + i].x;
+		else if (s.wrap) val = y[(size_t)(jt < 0 ? nyl - 1 : 0) * nx + i].x;
+		else val = (jt < 0) ? ghost_lo[i] : ghost_hi[i];
+		tile[tr][tx + 1] = val;
+	}
+	const Real cA = col_ok ? s.cA[i] : (Real)0;
+	const Real cP = col_ok ? s.cP[i] : (Real)0;
+	__syncthreads();
+
+#pragma unroll
+	for (int r = 0; r < kRPT; r++) {
+		const int j = j0 + ty + kBY * r;
+		if (!(j < nyl && col_ok)) continue;
+		const int tr = ty + kBY * r + 1;
+		const bool zero = absorb && ((s.has_row0 && j == 0) || (s.has_rowN && j == nyl - 1));
+		P k;
+		rhs_point<Real, MODEL>(own[r].x, tile[tr][tx], tile[tr][tx + 2], tile[tr - 1][tx + 1], tile[tr + 1][tx + 1], own[r].y, cA, s.cX, cP,
+		                       s.brow[j], s.ka4, zero, s.just_diffusion != 0, k.x, k.y);
+		ydot[(size_t)j * nx + i] = k;
+	}
+}
+
+// ---- layout adaptors -------------------------------------------------------------------------------------------
+template <typename Src, typename Real>
+__global__ void __launch_bounds__(256) crd_aos_to_planes_kernel(const Src *__restrict__ aos, Real *__restrict__ u, Real *__restrict__ v, size_t n)
+{
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+		u[q] = (Real)aos[2 * q];
+		v[q] = (Real)aos[2 * q + 1];
+	}
+}
+
+template <typename Dst, typename Real>
+__global__ void __launch_bounds__(256) crd_planes_to_aos_kernel(const Real *__restrict__ u, const Real *__restrict__ v, Dst *__restrict__ aos, size_t n)
+{
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+		aos[2 * q] = (Dst)u[q];
+		aos[2 * q + 1] = (Dst)v[q];
+	}
+}
+
+template <typename Real>
+__global__ void __launch_bounds__(256) crd_aos_row_extract_kernel(const Real *__restrict__ aos_row, Real *__restrict__ row, int nx)
+{
+	const int i = blockIdx.x * blockDim.x + threadIdx.x;
+	if (i < nx) row[i] = aos_row[2 * (size_t)i];
+}
+
+template <typename Real>
+__global__ void __launch_bounds__(256) crd_max_abs_kernel(const Real *__restrict__ u, size_t n, double *out)
+{
+	__shared__ double part[4];
+	double m = 0.0;
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+		const double a = fabs((double)u[q]);
+		m = (a > m || a != a) ? a : m;  // NaN propagates
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		const double o = __shfl_down(m, off, 64);
+		m = (o > m || o != o) ? o : m;
+	}
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 4; w++) m = (part[w] > m || part[w] != part[w]) ? part[w] : m;
+		// non-negative doubles order like their bit patterns; NaN (0x7ff8...) sorts above every finite value
+		atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(m));
+	}
+}
+
+inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
+
+template <typename Real, int MODEL>
+hipError_t launch_stage_t(const SlabDesc &d, const StageCall &c, int row_begin, int row_end, hipStream_t st)
+{
+	const Slab<Real> s = typed<Real>(d);
+	StageArgs<Real> a;
+	a.in_u = row0<Real>(c.yin.u, d.nx);
+	a.in_v = row0<Real>(c.yin.v, d.nx);
+	a.y0_u = row0<Real>(c.y0.u, d.nx);
+	a.y0_v = row0<Real>(c.y0.v, d.nx);
+	a.acc_u = row0<Real>(c.acc.u, d.nx);
+	a.acc_v = row0<Real>(c.acc.v, d.nx);
+	a.out_u = row0<Real>(c.yout.u, d.nx);
+	a.out_v = row0<Real>(c.yout.v, d.nx);
+	a.absorb = c.absorb;
+	switch (c.stage) {
+	case 1: a.h_out = (Real)(0.5 * c.dt); a.h_acc = (Real)(c.dt / 6.0); break;
+	case 2: a.h_out = (Real)(0.5 * c.dt); a.h_acc = (Real)(c.dt / 3.0); break;
+	case 3: a.h_out = (Real)c.dt; a.h_acc = (Real)(c.dt / 3.0); break;
+	case 4: a.h_out = (Real)0; a.h_acc = (Real)(c.dt / 6.0); break;
+	default: a.h_out = a.h_acc = (Real)0; break;
+	}
+	if (row_end <= row_begin) return hipSuccess;
+	const int nbx = (d.nx + kTX - 1) / kTX, nby = (row_end - row_begin + kTY - 1) / kTY;
+	const int nblocks = nbx * nby;
+	const dim3 block(kTX, kBY);
+	switch (c.stage) {
+	case 0: crd_rk4_stage_kernel<Real, MODEL, 0><<<nblocks, block, 0, st>>>(s, a, row_begin, row_end, nbx, nblocks); break;
+	case 1: crd_rk4_stage_kernel<Real, MODEL, 1><<<nblocks, block, 0, st>>>(s, a, row_begin, row_end, nbx, nblocks); break;
+	case 2: crd_rk4_stage_kernel<Real, MODEL, 2><<<nblocks, block, 0, st>>>(s, a, row_begin, row_end, nbx, nblocks); break;
+	case 3: crd_rk4_stage_kernel<Real, MODEL, 3><<<nblocks, block, 0, st>>>(s, a, row_begin, row_end, nbx, nblocks); break;
+	case 4: crd_rk4_stage_kernel<Real, MODEL, 4><<<nblocks, block, 0, st>>>(s, a, row_begin, row_end, nbx, nblocks); break;
+	default: return hipErrorInvalidValue;
+	}
+	return hipGetLastError();
+}
+
+template <typename Real, int MODEL>
+hipError_t launch_rhs_aos_t(const SlabDesc &d, int absorb, const void *y, void *ydot, const void *glo, const void *ghi, hipStream_t st)
+{
+	using P = typename Pair<Real>::type;
+	const Slab<Real> s = typed<Real>(d);
+	const int nbx = (d.nx + kTX - 1) / kTX, nby = (d.nyl + kTY - 1) / kTY;
+	const int nblocks = nbx * nby;
+	crd_rhs_aos_kernel<Real, MODEL><<<nblocks, dim3(kTX, kBY), 0, st>>>(s, static_cast<const P *>(y), static_cast<P *>(ydot),
+	                                                                  static_cast<const Real *>(glo), static_cast<const Real *>(ghi), absorb, nbx,
+	                                                                  nblocks);
+	return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_stage(int precision, const SlabDesc &d, const StageCall &c, int row_begin, int row_end, hipStream_t s)
+{
+	if (precision == CRD_PRECISION_F64)
+		return d.model == CRD_MODEL_FHN ? launch_stage_t<double, CRD_MODEL_FHN>(d, c, row_begin, row_end, s)
+		                                : launch_stage_t<double, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, s);
+	return d.model == CRD_MODEL_FHN ? launch_stage_t<float, CRD_MODEL_FHN>(d, c, row_begin, row_end, s)
+	                                : launch_stage_t<float, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, s);
+}
+
+const char *stage_kernel_name(int, int) { return "crd_rk4_stage_kernel"; }
+
+hipError_t launch_rhs_aos(int precision, const SlabDesc &d, int absorb, const void *y, void *ydot, const void *ghost_lo, const void *ghost_hi,
+                          hipStream_t s)
+{
+	if (precision == CRD_PRECISION_F64)
+		return d.model == CRD_MODEL_FHN ? launch_rhs_aos_t<double, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, s)
+		                                : launch_rhs_aos_t<double, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, s);
+	return d.model == CRD_MODEL_FHN ? launch_rhs_aos_t<float, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, s)
+	                                : launch_rhs_aos_t<float, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, s);
+}
+
+hipError_t launch_aos_to_planes(int precision, int src_is_f64, const void *aos, Planes dst, int nx, int nyl, hipStream_t s)
+{
+	const size_t n = (size_t)nx * (size_t)nyl;
+	if (n == 0) return hipSuccess;
+	const int g = grid_for(n);
+	if (precision == CRD_PRECISION_F64) {
+		if (!src_is_f64) return hipErrorInvalidValue;
+		crd_aos_to_planes_kernel<double, double><<<g, 256, 0, s>>>(static_cast<const double *>(aos), row0<double>(dst.u, nx), row0<double>(dst.v, nx), n);
+	} else if (src_is_f64) {
+		crd_aos_to_planes_kernel<double, float><<<g, 256, 0, s>>>(static_cast<const double *>(aos), row0<float>(dst.u, nx), row0<float>(dst.v, nx), n);
+	} else {
+		crd_aos_to_planes_kernel<float, float><<<g, 256, 0, s>>>(static_cast<const float *>(aos), row0<float>(dst.u, nx), row0<float>(dst.v, nx), n);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_planes_to_aos(int precision, int dst_is_f64, Planes src, void *aos, int nx, int nyl, hipStream_t s)
+{
+	const size_t n = (size_t)nx * (size_t)nyl;
+	if (n == 0) return hipSuccess;
+	const int g = grid_for(n);
+	if (precision == CRD_PRECISION_F64) {
+		if (!dst_is_f64) return hipErrorInvalidValue;
+		crd_planes_to_aos_kernel<double, double><<<g, 256, 0, s>>>(row0<double>(src.u, nx), row0<double>(src.v, nx), static_cast<double *>(aos), n);
+	} else if (dst_is_f64) {
+		crd_planes_to_aos_kernel<double, float><<<g, 256, 0, s>>>(row0<float>(src.u, nx), row0<float>(src.v, nx), static_cast<double *>(aos), n);
+	} else {
+		crd_planes_to_aos_kernel<float, float><<<g, 256, 0, s>>>(row0<float>(src.u, nx), row0<float>(src.v, nx), static_cast<float *>(aos), n);
+	}
+	return hipGetLastError();
+}
+
+hipError_t launch_aos_row_extract(int precision, const void *aos, void *row, int nx, int j, hipStream_t s)
+{
+	const int g = (nx + 255) / 256;
+	if (precision == CRD_PRECISION_F64)
+		crd_aos_row_extract_kernel<double><<<g, 256, 0, s>>>(static_cast<const double *>(aos) + 2 * (size_t)j * nx, static_cast<double *>(row), nx);
+	else
+		crd_aos_row_extract_kernel<float><<<g, 256, 0, s>>>(static_cast<const float *>(aos) + 2 * (size_t)j * nx, static_cast<float *>(row), nx);
+	return hipGetLastError();
+}
+
+hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s)
+{
+	const size_t n = (size_t)nx * (size_t)nyl;
+	hipError_t e = hipMemsetAsync(out_dev, 0, sizeof(double), s);
+	if (e != hipSuccess || n == 0) return e;
+	const int g = grid_for(n);
+	if (precision == CRD_PRECISION_F64)
+		crd_max_abs_kernel<double><<<g, 256, 0, s>>>(row0<double>(const_cast<void *>(u_plane), nx), n, out_dev);
+	else
+		crd_max_abs_kernel<float><<<g, 256, 0, s>>>(row0<float>(const_cast<void *>(u_plane), nx), n, out_dev);
+	return hipGetLastError();
+}
+
+}  // namespace crd

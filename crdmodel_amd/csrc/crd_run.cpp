@@ -1,0 +1,267 @@
+// crd_run.cpp -- command-line driver with the reference's surface: `<program> <ini file>` writes the per-subdomain
+// text files the reference's Python plotting / torus-mapping utilities read.  It replaces main() of the four
+// reference programs (src/FHNmodel_torus.cpp:148-497 and siblings); invoked through one of the alias names
+// FHNmodel_torus / FHNmodel_flat / GoldbeterModel_torus / GoldbeterModel_flat it takes exactly one argument, like
+// they do.  Time integration is fixed-step RK4 on the GPU (libcrd) instead of adaptive ARKode.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "crd.h"
+
+namespace {
+
+struct Options {
+	int model = -1, surface = -1;
+	int gpus = 0;        // 0 = take [Solver] gpus from the ini (default 1)
+	int devices = 0;     // number of physical devices to spread the slabs over (0 = as many as slabs)
+	double dt = -1.0;
+	int stepper = -1;
+	int precision = -1;
+	std::string outdir = ".";
+	std::string ini;
+	bool quiet = false;
+};
+
+[[noreturn]] void usage(const char *argv0, bool alias)
+{
+	if (alias) {
+		std::cerr << "Usage: " << argv0 << " <Config file path>";  // src/FHNmodel_torus.cpp:153
+	} else {
+		std::cerr << "Usage: " << argv0
+		          << " --model fhn|goldbeter --surface torus|flat [--gpus G] [--devices D] [--dt DT] [--stepper auto|staged|fused]\n"
+		             "       [--precision 64|32] [--outdir DIR] [--quiet] <Config file path>\n";
+	}
+	std::exit(EXIT_FAILURE);
+}
+
+bool preset_from_name(const std::string &base, Options *o)
+{
+	if (base == "FHNmodel_torus") { o->model = CRD_MODEL_FHN; o->surface = CRD_SURFACE_TORUS; return true; }
+	if (base == "FHNmodel_flat") { o->model = CRD_MODEL_FHN; o->surface = CRD_SURFACE_FLAT; return true; }
+	if (base == "GoldbeterModel_torus") { o->model = CRD_MODEL_GOLDBETER; o->surface = CRD_SURFACE_TORUS; return true; }
+	if (base == "GoldbeterModel_flat") { o->model = CRD_MODEL_GOLDBETER; o->surface = CRD_SURFACE_FLAT; return true; }
+	return false;
+}
+
+void banner(const crd_run_config &cfg, const crd_grid &g, int n_slabs, int64_t nyl0, double s0, double s1, double dt, int64_t steps_per_output)
+{
+	// Same lines as src/FHNmodel_torus.cpp:249-275 (and the Goldbeter variant, src/GoldbeterModel_torus.cpp:266-303),
+	// with rtol / atol replaced by the fixed step.
+	const crd_params &p = cfg.params;
+	const bool fhn = p.model == CRD_MODEL_FHN, torus = p.surface == CRD_SURFACE_TORUS;
+	std::cout << (fhn ? "\n2D FHN model PDE problem on a " : "\n Goldbeter model PDE problem on a ") << (torus ? "torus" : "flat surface") << ":\n";
+	std::cout << "   nprocs = " << n_slabs << "\n";
+	std::cout << "   nx = " << g.nx << "\n";
+	std::cout << "   ny = " << g.ny << "\n";
+	std::cout << "   nxl = " << g.nx << "\n";
+	std::cout << "   nyl = " << nyl0 << "\n";
+	std::cout << "   Diff = " << p.diffusion << "\n";
+	std::cout << "   Tfinal = " << cfg.t_final << "\n";
+	std::cout << "   Output timesteps = " << cfg.output_timestep << "\n";
+	if (torus) {
+		std::cout << "   Major circumference = " << p.surface_length << "\n";
+		std::cout << "   Minor circumference = " << p.surface_width << "\n";
+	} else {
+		std::cout << "   Surface length = " << p.surface_length << "\n";
+		std::cout << "   Surface width = " << p.surface_width << "\n";
+	}
+	if (fhn) std::cout << "   Absorbing boundary turn off time = " << p.t_boundary << "\n";
+	std::cout << "   Wavelength = " << cfg.wave_length * 100 << "%\n";
+	std::cout << "   Wavewidth = " << cfg.wave_width * 100 << "%\n";
+	if (fhn && torus) std::cout << "   Wave inside = " << cfg.wave_inside << "\n";
+	std::cout << "   integrator = classical RK4 on GPU, dt = " << dt << " (" << steps_per_output << " steps per output)\n";
+	if (!fhn && p.just_diffusion == 1) {
+		std::cout << "   Diffusion Only\n\n";
+		return;
+	}
+	std::cout << "   Include all variables in output = " << cfg.include_all_vars << "\n";
+	if (!fhn) std::cout << "   Absorbing boundary turn off time = " << p.t_boundary << "\n";
+	if (p.vary_beta == 0) {
+		std::cout << "   Beta = " << p.beta << "\n";
+		std::cout << "   Stable state values: " << (fhn ? "U = " : "Z = ") << s0 << (fhn ? ", V = " : ", Y = ") << s1 << "\n\n";
+	} else {
+		std::cout << "   Beta varied over " << (torus ? "torus" : "surface") << "\n";
+		if (!fhn) {
+			if (cfg.ic_type == 0) std::cout << "   Homogeneous ICs\n";
+			if (cfg.ic_type == 1) std::cout << "   ICs: initial perturbation\n";
+			if (cfg.ic_type == 2) std::cout << "   Random ICs\n";
+		}
+		std::cout << "\n";
+	}
+}
+
+int die(const char *what, int rc, crd_ctx *ctx)
+{
+	std::cerr << "\nCRD_ERROR: " << what << " failed with flag = " << rc << " (" << crd_status_string(rc) << ")";
+	const char *detail = crd_last_error(ctx);
+	if (detail && *detail) std::cerr << ": " << detail;
+	std::cerr << "\n\n";
+	return 1;
+}
+
+}  // namespace
+
+int main(int argc, char *argv[])
+{
+	Options o;
+	std::string base = argv[0];
+	const size_t slash = base.find_last_of('/');
+	if (slash != std::string::npos) base = base.substr(slash + 1);
+	const bool alias = preset_from_name(base, &o);
+
+	if (alias) {
+		if (argc != 2) usage(argv[0], true);  // src/FHNmodel_torus.cpp:151-155
+		o.ini = argv[1];
+	} else {
+		for (int a = 1; a < argc; a++) {
+			const std::string s = argv[a];
+			auto next = [&]() -> std::string {
+				if (a + 1 >= argc) usage(argv[0], false);
+				return argv[++a];
+			};
+			if (s == "--model") {
+				const std::string v = next();
+				o.model = v == "fhn" ? CRD_MODEL_FHN : v == "goldbeter" ? CRD_MODEL_GOLDBETER : -1;
+			} else if (s == "--surface") {
+				const std::string v = next();
+				o.surface = v == "torus" ? CRD_SURFACE_TORUS : v == "flat" ? CRD_SURFACE_FLAT : -1;
+			} else if (s == "--gpus") o.gpus = std::atoi(next().c_str());
+			else if (s == "--devices") o.devices = std::atoi(next().c_str());
+			else if (s == "--dt") o.dt = std::atof(next().c_str());
+			else if (s == "--outdir") o.outdir = next();
+			else if (s == "--quiet") o.quiet = true;
+			else if (s == "--precision") {
+				const std::string v = next();
+				o.precision = v == "32" ? CRD_PRECISION_F32 : v == "64" ? CRD_PRECISION_F64 : -2;
+			} else if (s == "--stepper") {
+				const std::string v = next();
+				o.stepper = v == "auto" ? CRD_STEPPER_AUTO : v == "staged" ? CRD_STEPPER_STAGED : v == "fused" ? CRD_STEPPER_FUSED : -2;
+			} else if (!s.empty() && s[0] == '-') usage(argv[0], false);
+			else if (o.ini.empty()) o.ini = s;
+			else usage(argv[0], false);
+		}
+		if (o.model < 0 || o.surface < 0 || o.ini.empty() || o.precision == -2 || o.stepper == -2) usage(argv[0], false);
+	}
+
+	crd_run_config cfg;
+	char err[512];
+	int rc = crd_config_load_ini(o.ini.c_str(), o.model, o.surface, &cfg, err, sizeof err);
+	if (rc != CRD_OK) {
+		std::cerr << "\nCRD_ERROR: cannot use " << o.ini << ": " << err << "\n\n";
+		return 1;
+	}
+	if (o.gpus > 0) cfg.n_gpus = o.gpus;
+	if (o.dt > 0) cfg.dt = o.dt;
+	if (o.stepper >= 0) cfg.stepper = o.stepper;
+	if (o.precision >= 0) cfg.params.precision = o.precision;
+
+	time_t start_t = 0, end_t = 0;
+	double total_t = 0, eta = 0;
+	time(&start_t);
+
+	crd_grid g;
+	if ((rc = crd_grid_from_params(&cfg.params, &g)) != CRD_OK) return die("crd_grid_from_params", rc, nullptr);
+	const int G = cfg.n_gpus;
+	const int ndev = o.devices > 0 ? o.devices : G;
+
+	double s0 = 0, s1 = 0;
+	if ((rc = crd_steady_state(cfg.params.model, cfg.params.beta, &s0, &s1)) != CRD_OK) return die("crd_steady_state", rc, nullptr);
+
+	// Output cadence (src/FHNmodel_torus.cpp:415-429): Nt outputs dTout apart; every interval is an integer number of
+	// equal RK4 steps no longer than the requested / stable step.
+	const int Nt = cfg.output_timestep;
+	const double dTout = cfg.t_final / Nt;
+	const double dt_cap = cfg.dt > 0 ? cfg.dt : cfg.dt_safety * crd_stable_dt(&cfg.params);
+	const int64_t steps_per_output = (int64_t)std::ceil(dTout / dt_cap - 1e-12);
+	const double dt = dTout / (double)steps_per_output;
+
+	std::vector<crd_ctx *> ctx((size_t)G, nullptr);
+	std::vector<crd_writer *> wr((size_t)G, nullptr);
+	std::vector<std::vector<double>> host((size_t)G);
+	auto cleanup = [&]() {
+		for (auto *w : wr) crd_writer_close(w);
+		for (auto *c : ctx) crd_destroy(c);
+	};
+	for (int k = 0; k < G; k++) {
+		if ((rc = crd_create(&cfg.params, k, G, k % ndev, &ctx[(size_t)k])) != CRD_OK) {
+			die("crd_create", rc, nullptr);
+			cleanup();
+			return 1;
+		}
+		crd_set_stepper(ctx[(size_t)k], G > 1 ? CRD_STEPPER_STAGED : cfg.stepper);
+	}
+	if ((rc = crd_comm_attach_local(ctx.data(), G)) != CRD_OK) {
+		die("crd_comm_attach_local", rc, ctx[0]);
+		cleanup();
+		return 1;
+	}
+
+	int64_t js0 = 0, je0 = 0;
+	crd_get_slab(ctx[0], &js0, &je0);
+	if (!o.quiet) banner(cfg, g, G, je0 - js0 + 1, s0, s1, dt, steps_per_output);
+
+	// Initial conditions, subdomain files, first output row (src/FHNmodel_torus.cpp:285-354,376-410).
+	for (int k = 0; k < G; k++) {
+		int64_t js, je;
+		crd_get_slab(ctx[(size_t)k], &js, &je);
+		host[(size_t)k].resize((size_t)(2 * g.nx * (je - js + 1)));
+		if ((rc = crd_initial_conditions(&cfg, js, je, host[(size_t)k].data())) != CRD_OK) {
+			die("crd_initial_conditions", rc, nullptr);
+			cleanup();
+			return 1;
+		}
+		if ((rc = crd_state_upload(ctx[(size_t)k], host[(size_t)k].data(), 1)) != CRD_OK) {
+			die("crd_state_upload", rc, ctx[(size_t)k]);
+			cleanup();
+			return 1;
+		}
+		if ((rc = crd_writer_open(&cfg, o.outdir.c_str(), k, G, &wr[(size_t)k])) != CRD_OK || (rc = crd_writer_write_row(wr[(size_t)k], host[(size_t)k].data())) != CRD_OK) {
+			die("crd_writer", rc, nullptr);
+			cleanup();
+			return 1;
+		}
+	}
+
+	int status = 0;
+	for (int iout = 0; iout < Nt; iout++) {
+		const double t = iout * dTout;
+		rc = crd_group_step_rk4(ctx.data(), G, t, dt, steps_per_output);
+		for (int k = 0; k < G && rc == CRD_OK; k++) rc = crd_state_download(ctx[(size_t)k], host[(size_t)k].data(), 1);
+		double peak = 0;
+		if (rc == CRD_OK) rc = crd_state_max_abs(ctx[0], &peak);
+		if (rc != CRD_OK || !std::isfinite(peak)) {
+			if (rc != CRD_OK) die("crd_group_step_rk4", rc, ctx[0]);
+			std::cerr << "Solver failure, stopping integration\n";  // src/FHNmodel_torus.cpp:433
+			status = 1;
+			break;
+		}
+		for (int k = 0; k < G; k++)
+			if ((rc = crd_writer_write_row(wr[(size_t)k], host[(size_t)k].data())) != CRD_OK) {
+				die("crd_writer_write_row", rc, nullptr);
+				status = 1;
+				break;
+			}
+		if (status) break;
+
+		// progress line, src/FHNmodel_torus.cpp:457-477
+		time(&end_t);
+		total_t += difftime(end_t, start_t);
+		start_t = end_t;
+		eta = (Nt - (iout + 1)) * (total_t / (iout + 1));
+		if (!o.quiet) {
+			if (iout > 0) std::printf("\r");
+			std::printf("   %3d %% | %3d min %2d sec elapsed | %3d min %2d sec remaining", 100 * (iout + 1) / Nt, (int)(total_t / 60), ((int)total_t % 60),
+			            (int)(eta / 60), ((int)eta % 60));
+			std::fflush(stdout);
+		}
+	}
+	if (!o.quiet) std::cout << "\n   ----------------------\n";
+	cleanup();
+	return status;
+}

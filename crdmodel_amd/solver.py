@@ -1,0 +1,251 @@
+"""Host-side mirror of the reference's interface for the RHS path, on top of the libcrd C ABI.
+
+Names follow the reference (/root/reference/src/FHNmodel_torus.cpp): a `Slab` is one subdomain (UserData) living
+on one GPU; `Slab.f(t, y)` is the ARKRhsFn `f(t, y, ydot, user_data)` (:504); `Slab.step_rk4` replaces the
+`ARKode(...)` call (:423).  Vectors are numpy arrays in the reference's layout, shape (nyl, nx, 2) = AoS [var0, var1],
+theta fastest.  All arithmetic happens in the HIP kernels; nothing here computes on the CPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as capi
+from ._capi import (MODELS, SURFACES, STEPPERS, PRECISION_F32, PRECISION_F64, CrdError, Grid, Params,  # noqa: F401
+                    RunConfig, check, lib)
+
+
+def make_params(model, surface, nx, surface_length, surface_width, diffusion, beta, *, ny=0, beta_min=0.0, beta_max=0.0,
+                vary_beta=0, just_diffusion=0, t_boundary=0.0, precision="f64"):
+    p = Params()
+    p.model = MODELS[model] if isinstance(model, str) else model
+    p.surface = SURFACES[surface] if isinstance(surface, str) else surface
+    p.nx, p.ny = nx, ny
+    p.surface_length, p.surface_width = surface_length, surface_width
+    p.diffusion, p.beta, p.beta_min, p.beta_max = diffusion, beta, beta_min, beta_max
+    p.vary_beta, p.just_diffusion = vary_beta, just_diffusion
+    p.t_boundary = t_boundary
+    p.precision = {"f64": PRECISION_F64, "f32": PRECISION_F32}[precision] if isinstance(precision, str) else precision
+    return p
+
+
+def grid_of(params):
+    g = Grid()
+    check(lib().crd_grid_from_params(C.byref(params), C.byref(g)), "crd_grid_from_params")
+    return g
+
+
+def slab_extents(ny, slab, n_slabs):
+    js, je = C.c_int64(), C.c_int64()
+    check(lib().crd_slab_extents(ny, slab, n_slabs, C.byref(js), C.byref(je)), "crd_slab_extents")
+    return js.value, je.value
+
+
+def steady_state(model, beta):
+    a, b = C.c_double(), C.c_double()
+    m = MODELS[model] if isinstance(model, str) else model
+    check(lib().crd_steady_state(m, beta, C.byref(a), C.byref(b)), "crd_steady_state")
+    return a.value, b.value
+
+
+def stable_dt(params):
+    return lib().crd_stable_dt(C.byref(params))
+
+
+def load_ini(path, model, surface):
+    cfg = RunConfig()
+    err = C.create_string_buffer(512)
+    m = MODELS[model] if isinstance(model, str) else model
+    s = SURFACES[surface] if isinstance(surface, str) else surface
+    rc = lib().crd_config_load_ini(str(path).encode(), m, s, C.byref(cfg), err, len(err))
+    if rc != capi.OK:
+        raise CrdError(rc, "crd_config_load_ini", err.value.decode())
+    return cfg
+
+
+def run_config(params, *, wave_length=0.1, wave_width=0.5, wave_inside=0, output_timestep=1, t_final=1.0,
+               include_all_vars=0, ic_type=0, dt=0.0, dt_safety=0.8, n_gpus=1, stepper=capi.STEPPER_AUTO):
+    cfg = RunConfig()
+    cfg.params = params
+    cfg.wave_length, cfg.wave_width, cfg.wave_inside = wave_length, wave_width, wave_inside
+    cfg.output_timestep, cfg.t_final = output_timestep, t_final
+    cfg.include_all_vars, cfg.ic_type = include_all_vars, ic_type
+    cfg.dt, cfg.dt_safety, cfg.n_gpus, cfg.stepper = dt, dt_safety, n_gpus, stepper
+    return cfg
+
+
+def initial_conditions(cfg, js=None, je=None):
+    """Rows [js, je] of the reference's initial state as float64 (nyl, nx, 2)."""
+    g = grid_of(cfg.params)
+    js = 0 if js is None else js
+    je = g.ny - 1 if je is None else je
+    y = np.empty((je - js + 1, g.nx, 2), dtype=np.float64)
+    check(lib().crd_initial_conditions(C.byref(cfg), js, je, y.ctypes.data), "crd_initial_conditions")
+    return y
+
+
+class Writer:
+    """Per-subdomain text files in the reference's format (/root/reference/src/FHNmodel_torus.cpp:376-410,438-455)."""
+
+    def __init__(self, cfg, directory, slab=0, n_slabs=1):
+        self._h = C.c_void_p()
+        check(lib().crd_writer_open(C.byref(cfg), str(directory).encode(), slab, n_slabs, C.byref(self._h)), "crd_writer_open")
+
+    def write_row(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        check(lib().crd_writer_write_row(self._h, y.ctypes.data), "crd_writer_write_row")
+
+    def close(self):
+        if self._h:
+            h, self._h = self._h, None
+            check(lib().crd_writer_close(h), "crd_writer_close")
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+
+class Slab:
+    """One phi-slab of the grid resident on one GPU (crd_ctx)."""
+
+    def __init__(self, params, slab=0, n_slabs=1, device=0):
+        self._h = C.c_void_p()
+        self.params = params
+        rc = lib().crd_create(C.byref(params), slab, n_slabs, device, C.byref(self._h))
+        if rc != capi.OK:
+            self._h = None
+            raise CrdError(rc, "crd_create", lib().crd_last_error(None).decode())
+        g = Grid()
+        check(lib().crd_get_grid(self._h, C.byref(g)), "crd_get_grid", self._h)
+        self.grid = g
+        js, je = C.c_int64(), C.c_int64()
+        check(lib().crd_get_slab(self._h, C.byref(js), C.byref(je)), "crd_get_slab", self._h)
+        self.js, self.je = js.value, je.value
+        self.nx, self.nyl = g.nx, je.value - js.value + 1
+        self.slab, self.n_slabs = slab, n_slabs
+        self.dtype = np.float64 if params.precision == PRECISION_F64 else np.float32
+
+    # -- lifecycle ---------------------------------------------------------------------------------------------
+    def close(self):
+        if self._h:
+            lib().crd_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def _check(self, rc, where):
+        check(rc, where, self._h)
+
+    # -- state -------------------------------------------------------------------------------------------------
+    def upload(self, y):
+        y = np.ascontiguousarray(y)
+        assert y.shape == (self.nyl, self.nx, 2), (y.shape, (self.nyl, self.nx, 2))
+        if y.dtype == np.float64:
+            self._check(lib().crd_state_upload(self._h, y.ctypes.data, 1), "crd_state_upload")
+        elif y.dtype == np.float32 and self.dtype == np.float32:
+            self._check(lib().crd_state_upload(self._h, y.ctypes.data, 0), "crd_state_upload")
+        else:
+            raise TypeError("state must be float64, or float32 for an f32 context")
+
+    def download(self, dtype=np.float64):
+        y = np.empty((self.nyl, self.nx, 2), dtype=dtype)
+        self._check(lib().crd_state_download(self._h, y.ctypes.data, 1 if y.dtype == np.float64 else 0), "crd_state_download")
+        return y
+
+    # -- the RHS callback --------------------------------------------------------------------------------------
+    def f(self, t, y):
+        """ydot = f(t, y) for this slab's AoS vector (host arrays in the device precision)."""
+        y = np.ascontiguousarray(y, dtype=self.dtype)
+        assert y.shape == (self.nyl, self.nx, 2)
+        ydot = np.empty_like(y)
+        self._check(lib().crd_rhs_host(self._h, t, y.ctypes.data, ydot.ctypes.data), "crd_rhs_host")
+        return ydot
+
+    # -- time stepping -----------------------------------------------------------------------------------------
+    def set_stepper(self, stepper):
+        s = STEPPERS[stepper] if isinstance(stepper, str) else stepper
+        self._check(lib().crd_set_stepper(self._h, s), "crd_set_stepper")
+
+    def step_rk4(self, t0, dt, nsteps, sync=True):
+        self._check(lib().crd_step_rk4(self._h, t0, dt, nsteps), "crd_step_rk4")
+        if sync:
+            self.synchronize()
+
+    def step_rk4_timed(self, t0, dt, nsteps):
+        ms, kms, lps = C.c_double(), C.c_double(), C.c_int()
+        self._check(lib().crd_step_rk4_timed(self._h, t0, dt, nsteps, C.byref(ms), C.byref(kms), C.byref(lps)), "crd_step_rk4_timed")
+        return ms.value, kms.value, lps.value
+
+    def synchronize(self):
+        self._check(lib().crd_synchronize(self._h), "crd_synchronize")
+
+    def dominant_kernel(self):
+        return lib().crd_dominant_kernel_name(self._h).decode()
+
+    def max_abs(self):
+        v = C.c_double()
+        self._check(lib().crd_state_max_abs(self._h, C.byref(v)), "crd_state_max_abs")
+        return v.value
+
+    # -- RCCL wiring -------------------------------------------------------------------------------------------
+    def init_rccl(self, unique_id):
+        buf = C.create_string_buffer(bytes(unique_id), 128)
+        self._check(lib().crd_comm_init_rccl(self._h, buf), "crd_comm_init_rccl")
+
+
+def rccl_unique_id():
+    buf = C.create_string_buffer(128)
+    check(lib().crd_comm_unique_id(buf), "crd_comm_unique_id")
+    return buf.raw
+
+
+class LocalGroup:
+    """All slabs of one run inside this process (one host thread drives every GPU, or several slabs on one GPU)."""
+
+    def __init__(self, params, n_slabs, devices=None):
+        devices = devices or [0] * n_slabs
+        self.slabs = [Slab(params, k, n_slabs, devices[k]) for k in range(n_slabs)]
+        self._arr = (C.c_void_p * n_slabs)(*[s.handle for s in self.slabs])
+        check(lib().crd_comm_attach_local(self._arr, n_slabs), "crd_comm_attach_local", self.slabs[0].handle)
+        self.grid = self.slabs[0].grid
+
+    def upload(self, y):
+        for s in self.slabs:
+            s.upload(y[s.js:s.je + 1])
+
+    def download(self):
+        return np.concatenate([s.download() for s in self.slabs], axis=0)
+
+    def step_rk4(self, t0, dt, nsteps):
+        check(lib().crd_group_step_rk4(self._arr, len(self.slabs), t0, dt, nsteps), "crd_group_step_rk4", self.slabs[0].handle)
+        for s in self.slabs:
+            s.synchronize()
+
+    def set_stepper(self, stepper):
+        for s in self.slabs:
+            s.set_stepper(stepper)
+
+    def close(self):
+        for s in self.slabs:
+            s.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()

@@ -1,0 +1,206 @@
+/*
+ * crd.h -- C ABI of libcrd: the MI355X-native replacement for CRDModel's per-timestep RHS path.
+ *
+ * Everything here is plain C: POD structs, pointers and sizes, `int` status returns (0 = ok, negative =
+ * crd_status), no exceptions cross the boundary, no torch/HIP types in any signature.  Each entry point names
+ * the reference interface it replaces (paths under the reference tree, e.g. src/FHNmodel_torus.cpp).
+ *
+ * Field layout at the boundary is the reference's own: state vectors are AoS pairs [var0, var1] per grid point,
+ * theta / x (index i) fastest, IDX(i,j) = 2 i + 2 j nxl (src/FHNmodel_torus.cpp:60); var0 is the diffusing
+ * variable (FHN u, Goldbeter Z), var1 the local one (FHN v, Goldbeter Y).  A context owns one phi-slab
+ * [js, je] x [0, nx-1] of the global grid (the reference's subdomain with dims = {1, G}).
+ */
+#ifndef CRD_H
+#define CRD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRD_ABI_VERSION 1
+
+typedef enum crd_status {
+	CRD_OK = 0,
+	CRD_EINVAL = -1,   /* bad argument / inconsistent parameters */
+	CRD_ENOMEM = -2,   /* host or device allocation failed */
+	CRD_EHIP = -3,     /* a HIP runtime call failed (no GPU, launch error, ...) */
+	CRD_ERCCL = -4,    /* an RCCL call failed */
+	CRD_EIO = -5,      /* file could not be read / written */
+	CRD_EPARSE = -6,   /* malformed ini file or missing mandatory key */
+	CRD_ESTATE = -7    /* call not valid in the context's current state */
+} crd_status;
+
+enum { CRD_MODEL_FHN = 0, CRD_MODEL_GOLDBETER = 1 };
+enum { CRD_SURFACE_TORUS = 0, CRD_SURFACE_FLAT = 1 };
+enum { CRD_PRECISION_F64 = 0, CRD_PRECISION_F32 = 1 };
+
+/* Which RK4 implementation crd_step_rk4 runs (results agree to round-off). */
+enum {
+	CRD_STEPPER_AUTO = 0,
+	CRD_STEPPER_STAGED = 1, /* four stage kernels per step, one halo row exchanged per stage */
+	CRD_STEPPER_FUSED = 2   /* one kernel per step (all four stages on chip), four halo rows per step */
+};
+
+/* Halo transport between the slabs of one run. */
+enum {
+	CRD_HALO_SELF = 0,  /* single slab: periodic wrap inside the kernels */
+	CRD_HALO_LOCAL = 1, /* several contexts in one process (any devices): device-to-device copies */
+	CRD_HALO_RCCL = 2   /* one context per process / GPU: ncclSend / ncclRecv over xGMI */
+};
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Parameters of the hot path: what f() reads from UserData and from the file-scope globals
+ * (src/FHNmodel_torus.cpp:80-94,97-122; src/GoldbeterModel_torus.cpp:91-106).
+ * --------------------------------------------------------------------------------------------------------- */
+typedef struct crd_params {
+	int32_t model;          /* CRD_MODEL_* */
+	int32_t surface;        /* CRD_SURFACE_* */
+	int64_t nx;             /* thetaMesh / xMesh */
+	int64_t ny;             /* 0 = derive as the reference does (:193 / flat :190-192); >0 = phiMesh override */
+	double surface_length;  /* surfaceLength: major circumference / flat length */
+	double surface_width;   /* surfaceWidth:  minor circumference / flat width */
+	double diffusion;       /* DIFF */
+	double beta;            /* BETA */
+	double beta_min;        /* BETAMIN */
+	double beta_max;        /* BETAMAX */
+	int32_t vary_beta;      /* VARYBETA */
+	int32_t just_diffusion; /* JUST_DIFFUSION (Goldbeter) */
+	double t_boundary;      /* TBOUNDARY */
+	int32_t precision;      /* CRD_PRECISION_*: arithmetic and storage type on the device */
+	int32_t reserved;
+} crd_params;
+
+/* Derived geometry (src/FHNmodel_torus.cpp:186-193,233-234; src/FHNmodel_flat.cpp:172-175,190-192,230-231). */
+typedef struct crd_grid {
+	int64_t nx, ny;
+	double dx, dy;
+	double xmin, xmax, ymin, ymax;
+	double R, r;            /* torus radii; 0 for flat */
+} crd_grid;
+
+/* Driver-level configuration: everything main() reads from the ini file (src/FHNmodel_torus.cpp:158-174,
+ * src/FHNmodel_flat.cpp:157-170, src/GoldbeterModel_torus.cpp:174-187, src/GoldbeterModel_flat.cpp:169-184),
+ * plus this build's extension keys. */
+typedef struct crd_run_config {
+	crd_params params;
+	double wave_length;       /* waveLength */
+	double wave_width;        /* waveWidth */
+	int32_t wave_inside;      /* waveInside (torus) */
+	int32_t output_timestep;  /* outputTimestep = Nt */
+	double t_final;           /* tFinal */
+	int32_t include_all_vars; /* includeAllVars */
+	int32_t ic_type;          /* icType (Goldbeter flat) */
+	/* extensions (absent keys take these defaults) */
+	double dt;                /* [Solver] dt: fixed RK4 step; 0 = safety * crd_stable_dt */
+	double dt_safety;         /* [Solver] dtSafety, default 0.8 */
+	int32_t n_gpus;           /* [Solver] gpus, default 1 */
+	int32_t stepper;          /* [Solver] stepper: CRD_STEPPER_* */
+} crd_run_config;
+
+typedef struct crd_ctx crd_ctx;
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Host-side helpers (no GPU needed).
+ * --------------------------------------------------------------------------------------------------------- */
+
+int crd_abi_version(void);
+const char *crd_status_string(int status);
+
+/* Replaces boost::property_tree::ini_parser::read_ini + the pt.get<T>() block of main()
+ * (src/FHNmodel_torus.cpp:158-174 and the three siblings).  The program's own mesh key is preferred
+ * (thetaMesh for FHN, xMesh for Goldbeter) but either is accepted; keys the reference program does not read
+ * are optional; a missing mandatory key is CRD_EPARSE (the reference aborts on ptree_bad_path).  err (may be
+ * NULL) receives a message. */
+int crd_config_load_ini(const char *path, int model, int surface, crd_run_config *cfg, char *err, size_t err_len);
+
+/* Geometry scalars a9: r, R, ny, dx, dy, domain bounds. */
+int crd_grid_from_params(const crd_params *p, crd_grid *g);
+
+/* phi-slab extents: SetupDecomp (src/FHNmodel_torus.cpp:750-755) with dims = {1, n_slabs}. */
+int crd_slab_extents(int64_t ny, int slab, int n_slabs, int64_t *js, int64_t *je);
+
+/* Stable state used by the initial conditions and the banner: FHN analytic (src/FHNmodel_torus.cpp:242-244);
+ * Goldbeter fixed point, computed natively instead of popen("SolveGoldbeterODE.py")
+ * (src/GoldbeterModel_torus.cpp:254-261). */
+int crd_steady_state(int model, double beta, double *s0, double *s1);
+
+/* Initial conditions of rows [js, je] in the boundary layout (AoS doubles, 2*nx*(je-js+1) values):
+ * src/FHNmodel_torus.cpp:285-354, src/FHNmodel_flat.cpp:280-319, src/GoldbeterModel_torus.cpp:313-414,
+ * src/GoldbeterModel_flat.cpp:309-379. */
+int crd_initial_conditions(const crd_run_config *cfg, int64_t js, int64_t je, double *y_aos);
+
+/* Largest classical-RK4-stable step of the linearised diffusion operator on this grid (2.785 / lambda_max). */
+double crd_stable_dt(const crd_params *p);
+
+/* Output files of one slab, byte-compatible with src/FHNmodel_torus.cpp:376-410,438-455:
+ * <Model>_<surface>_subdomain.%03i.txt, <Model>_<surface>_<var0>.%03i.txt, <..>_<var1>.%03i.txt in `dir`. */
+typedef struct crd_writer crd_writer;
+int crd_writer_open(const crd_run_config *cfg, const char *dir, int slab, int n_slabs, crd_writer **out);
+int crd_writer_write_row(crd_writer *w, const double *y_aos); /* one output time: nyl*nxl values per file */
+int crd_writer_close(crd_writer *w);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * Device context: replaces UserData + InitUserData / SetupDecomp / FreeUserData
+ * (src/FHNmodel_torus.cpp:97-122,708-772,953-997).  Not thread-safe; calls on one context must be serialised.
+ * --------------------------------------------------------------------------------------------------------- */
+
+/* slab / n_slabs: which phi-slab of the global grid this context owns; device: HIP device ordinal. */
+int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx **out);
+void crd_destroy(crd_ctx *ctx);
+const char *crd_last_error(const crd_ctx *ctx); /* never NULL; ctx may be NULL (creation errors) */
+
+int crd_get_grid(const crd_ctx *ctx, crd_grid *g);
+int crd_get_slab(const crd_ctx *ctx, int64_t *js, int64_t *je);
+
+/* Multi-slab wiring.  LOCAL: give every context of the run the full array (same process).
+ * RCCL: rank r of n_slabs ranks calls crd_comm_init_rccl with the 128-byte id rank 0 obtained from
+ * crd_comm_unique_id and distributed by any means (MPI_Bcast, torch.distributed, a file). */
+int crd_comm_attach_local(crd_ctx *const *ctxs, int n_slabs);
+int crd_comm_unique_id(void *id128);
+int crd_comm_init_rccl(crd_ctx *ctx, const void *id128);
+
+/* State transfer in the boundary layout.  host_is_f64 = 1: host buffer holds doubles whatever the device
+ * precision (converted on the device); 0: host buffer holds the device precision. */
+int crd_state_upload(crd_ctx *ctx, const void *y_aos_host, int host_is_f64);
+int crd_state_download(crd_ctx *ctx, void *y_aos_host, int host_is_f64);
+
+/* One RHS evaluation, the ARKRhsFn `f(t, y, ydot, user_data)` of src/FHNmodel_torus.cpp:126,504-667 (and
+ * siblings): halo exchange + diffusion + kinetics, writes every element of ydot, does not modify y.
+ * y / ydot are this slab's AoS vectors in the device precision; *_host takes host pointers (staged through
+ * device memory), *_device takes device pointers on the context's device.  Returns 0, or <0 like the
+ * reference's f() returns -1 when Exchange fails (:522). */
+int crd_rhs_host(crd_ctx *ctx, double t, const void *y_aos, void *ydot_aos);
+int crd_rhs_device(crd_ctx *ctx, double t, const void *y_aos_dev, void *ydot_aos_dev);
+
+/* Fast path that never leaves the GPU: nsteps classical RK4 steps of size dt on the context's resident state,
+ * stage k of step n evaluated at t0 + n dt + c_k dt (replaces the ARKode(...) call, src/FHNmodel_torus.cpp:423).
+ * Asynchronous; crd_synchronize() waits.  With several slabs every context of the run must make the same call. */
+int crd_set_stepper(crd_ctx *ctx, int stepper);
+int crd_step_rk4(crd_ctx *ctx, double t0, double dt, int64_t nsteps);
+int crd_synchronize(crd_ctx *ctx);
+
+/* LOCAL groups (several slabs driven by one host thread): the same two operations on every slab of the run in
+ * lockstep; ctxs[k] must be slab k of n.  y[k] / ydot[k] are device pointers on ctxs[k]'s device. */
+int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps);
+int crd_group_rhs_device(crd_ctx *const *ctxs, int n, double t, const void *const *y_aos_dev, void *const *ydot_aos_dev);
+
+/* Same as crd_step_rk4 but bracketed by HIP events on the context's compute stream; blocks until done.
+ * ms_total: device time of the whole batch; kernel_ms: average duration of one launch of the dominant kernel
+ * (the fused step kernel, or the stage-2/3 kernel of the staged stepper), measured by per-launch events on a
+ * subset of the steps; launches: how many launches of that kernel one step makes. */
+int crd_step_rk4_timed(crd_ctx *ctx, double t0, double dt, int64_t nsteps, double *ms_total, double *kernel_ms,
+                       int *launches_per_step);
+
+/* Name of the dominant kernel as it appears in a rocprofv3 kernel trace (static string). */
+const char *crd_dominant_kernel_name(const crd_ctx *ctx);
+
+/* max |var0| over the slab (blow-up guard; synchronises). */
+int crd_state_max_abs(crd_ctx *ctx, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CRD_H */
