@@ -163,7 +163,7 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, S
 				pav[r] = a.acc_v[off + i];
 			}
 		}
-		if (j < row_end) tile[ty + kBY * r + 1][tx + 1] = uC[r];  // rows past the range belong to the halo loader below
+		if (j < row_end && col_ok) tile[ty + kBY * r + 1][tx + 1] = uC[r];  // rows past the range belong to the halo loader, columns past nx to the wrap writer
 	}
 	// Halo rows j0-1 (wave 0) and min(j0+kTY, row_end) (wave 1): ghost rows of the slab, or the wrapped row.
 	if (ty < 2 && col_ok) {
@@ -237,7 +237,7 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, con
 			if (tx == 0) tile[ty + kBY * r + 1][0] = row[iw].x;
 			if (last_col) tile[ty + kBY * r + 1][tx + 2] = row[ie].x;
 		}
-		if (j < nyl) tile[ty + kBY * r + 1][tx + 1] = own[r].x;
+		if (j < nyl && col_ok) tile[ty + kBY * r + 1][tx + 1] = own[r].x;
 	}
 	if (ty < 2 && col_ok) {
 		const int jt = (ty == 0) ? j0 - 1 : ((j0 + kTY < nyl) ? j0 + kTY : nyl);
