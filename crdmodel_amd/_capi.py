@@ -4,7 +4,9 @@ There is no Python or CPU fallback: if libcrd.so is missing or cannot be loaded,
 raises, and any device call without a GPU returns CRD_EHIP which `check()` turns into an exception.
 """
 import ctypes as C
+import importlib.util
 import os
+import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libcrd.so")
@@ -44,6 +46,12 @@ class Grid(C.Structure):
     ]
 
 
+class HaloOp(C.Structure):
+    """crd_halo_op"""
+
+    _fields_ = [("is_send", C.c_int32), ("peer", C.c_int32), ("row_begin", C.c_int64), ("row_count", C.c_int64)]
+
+
 class RunConfig(C.Structure):
     """crd_run_config"""
 
@@ -80,6 +88,7 @@ _SIGNATURES = {
     "crd_comm_attach_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "crd_comm_unique_id": (C.c_int, [_vp]),
     "crd_comm_init_rccl": (C.c_int, [_vp, _vp]),
+    "crd_halo_plan": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(HaloOp)]),
     "crd_state_upload": (C.c_int, [_vp, _vp, C.c_int]),
     "crd_state_download": (C.c_int, [_vp, _vp, C.c_int]),
     "crd_rhs_host": (C.c_int, [_vp, C.c_double, _vp, _vp]),
@@ -107,10 +116,29 @@ class CrdError(RuntimeError):
         super().__init__(msg)
 
 
+def _one_hip_runtime():
+    """Keep ONE HIP runtime in the process.  PyTorch bundles its own libamdhip64 under the same SONAME as /opt/rocm's.
+    When PyTorch is installed but not imported yet, map its copy first and let libcrd bind to it by SONAME -- the same
+    pairing bench.py gets by importing torch first -- so a later `import torch` finds its own runtime already in place.
+    (RCCL is not touched here: libcrd binds it lazily with dlopen at the first crd_comm_* call.)
+    CRD_SYSTEM_ROCM=1 keeps /opt/rocm's runtime."""
+    if "torch" in sys.modules or os.environ.get("CRD_SYSTEM_ROCM") == "1":
+        return
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    libdir = os.path.join(os.path.dirname(spec.origin), "lib")
+    for name in ("libamdhip64.so",):
+        path = os.path.join(libdir, name)
+        if os.path.exists(path):
+            C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
 def lib():
     """Load libcrd.so (built in-tree by crdmodel_amd.build / `make -C crdmodel_amd/csrc`)."""
     global _lib
     if _lib is None:
+        _one_hip_runtime()
         if not os.path.exists(LIB_PATH):
             raise ImportError(
                 "libcrd.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "

@@ -1,7 +1,8 @@
 // crd_context.cpp -- the device context behind the C ABI: memory, streams, halo transports, the RK4 drivers.
 // Host code only (compiled by hipcc for the HIP runtime API); kernels live in crd_kernels.hip / crd_fused.hip.
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // types and prototypes only; the library is bound with dlopen at first use
 
 #include <algorithm>
 #include <cmath>
@@ -16,6 +17,54 @@ using namespace crd;
 
 namespace {
 thread_local std::string g_create_error;  // crd_last_error(NULL)
+
+// RCCL is bound at first use, not at load time: single-GPU runs never map the library, and a process that already
+// carries an RCCL (PyTorch bundles one under the same SONAME) shares that copy instead of loading a second one.
+struct RcclApi {
+	void *handle = nullptr;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	std::string error;
+
+	bool load()
+	{
+		if (handle) return true;
+		if (!error.empty()) return false;
+		for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+			handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+			if (handle) break;
+		}
+		if (!handle) {
+			error = std::string("cannot load librccl: ") + dlerror();
+			return false;
+		}
+		auto sym = [&](const char *n) {
+			void *p = dlsym(handle, n);
+			if (!p && error.empty()) error = std::string("librccl lacks ") + n;
+			return p;
+		};
+		GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+		CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+		CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+		GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+		GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+		Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+		Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+		GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+		if (!error.empty()) {
+			handle = nullptr;
+			return false;
+		}
+		return true;
+	}
+};
+RcclApi g_rccl;
 }
 
 struct crd_ctx {
@@ -71,7 +120,7 @@ int fail(crd_ctx *c, int code, const std::string &msg)
 #define NCCL_TRY(ctx, expr)                                                                                        \
 	do {                                                                                                           \
 		ncclResult_t r_ = (expr);                                                                                  \
-		if (r_ != ncclSuccess) return fail((ctx), CRD_ERCCL, std::string(#expr) + ": " + ncclGetErrorString(r_)); \
+		if (r_ != ncclSuccess) return fail((ctx), CRD_ERCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
 	} while (0)
 
 int set_device(crd_ctx *c)
@@ -124,20 +173,19 @@ int resolve_stepper(const crd_ctx *c)
 
 int exchange_rccl(crd_ctx *c, Planes pl, int depth, bool with_v)
 {
-	const int prev = (c->slab + c->n_slabs - 1) % c->n_slabs, next = (c->slab + 1) % c->n_slabs;
 	const size_t count = (size_t)depth * (size_t)c->nx;
 	const ncclDataType_t dt = c->p.precision == CRD_PRECISION_F64 ? ncclDouble : ncclFloat;
 	void *fields[2] = {pl.u, pl.v};
-	NCCL_TRY(c, ncclGroupStart());
-	for (int f = 0; f < (with_v ? 2 : 1); f++) {
-		// Order matters when prev == next (two slabs, or a self ring): the peer's first receive is its ghost_lo, which
-		// must get this slab's LAST rows, so those are sent first.
-		NCCL_TRY(c, ncclSend(c->row_ptr(fields[f], c->nyl - depth), count, dt, next, c->nccl, c->comm));
-		NCCL_TRY(c, ncclSend(c->row_ptr(fields[f], 0), count, dt, prev, c->nccl, c->comm));
-		NCCL_TRY(c, ncclRecv(c->row_ptr(fields[f], -depth), count, dt, prev, c->nccl, c->comm));
-		NCCL_TRY(c, ncclRecv(c->row_ptr(fields[f], c->nyl), count, dt, next, c->nccl, c->comm));
-	}
-	NCCL_TRY(c, ncclGroupEnd());
+	crd_halo_op ops[4];
+	if (crd_halo_plan(c->slab, c->n_slabs, c->nyl, depth, ops) != CRD_OK) return fail(c, CRD_EINVAL, "bad halo plan");
+	NCCL_TRY(c, g_rccl.GroupStart());
+	for (int f = 0; f < (with_v ? 2 : 1); f++)
+		for (const crd_halo_op &op : ops) {
+			void *rows = c->row_ptr(fields[f], op.row_begin);
+			if (op.is_send) NCCL_TRY(c, g_rccl.Send(rows, count, dt, op.peer, c->nccl, c->comm));
+			else NCCL_TRY(c, g_rccl.Recv(rows, count, dt, op.peer, c->nccl, c->comm));
+		}
+	NCCL_TRY(c, g_rccl.GroupEnd());
 	return CRD_OK;
 }
 
@@ -444,7 +492,7 @@ void crd_destroy(crd_ctx *c)
 	(void)hipSetDevice(c->device);
 	if (c->compute) (void)hipStreamSynchronize(c->compute);
 	if (c->comm) (void)hipStreamSynchronize(c->comm);
-	if (c->nccl) (void)ncclCommDestroy(c->nccl);
+	if (c->nccl && g_rccl.handle) (void)g_rccl.CommDestroy(c->nccl);
 	for (auto &pl : c->plane)
 		for (void *q : pl)
 			if (q) (void)hipFree(q);
@@ -506,7 +554,8 @@ int crd_comm_unique_id(void *id128)
 	if (!id128) return CRD_EINVAL;
 	static_assert(sizeof(ncclUniqueId) == 128, "RCCL unique id is 128 bytes");
 	ncclUniqueId id;
-	if (ncclGetUniqueId(&id) != ncclSuccess) return fail(nullptr, CRD_ERCCL, "ncclGetUniqueId failed");
+	if (!g_rccl.load()) return fail(nullptr, CRD_ERCCL, g_rccl.error);
+	if (g_rccl.GetUniqueId(&id) != ncclSuccess) return fail(nullptr, CRD_ERCCL, "ncclGetUniqueId failed");
 	std::memcpy(id128, &id, sizeof id);
 	return CRD_OK;
 }
@@ -515,10 +564,11 @@ int crd_comm_init_rccl(crd_ctx *c, const void *id128)
 {
 	if (!c || !id128) return CRD_EINVAL;
 	if (c->nccl) return fail(c, CRD_ESTATE, "RCCL communicator already initialised");
+	if (!g_rccl.load()) return fail(c, CRD_ERCCL, g_rccl.error);
 	if (int rc = set_device(c)) return rc;
 	ncclUniqueId id;
 	std::memcpy(&id, id128, sizeof id);
-	NCCL_TRY(c, ncclCommInitRank(&c->nccl, c->n_slabs, id, c->slab));
+	NCCL_TRY(c, g_rccl.CommInitRank(&c->nccl, c->n_slabs, id, c->slab));
 	c->halo = CRD_HALO_RCCL;
 	c->desc.wrap = 0;  // ghosts come from the ring, also when the ring is this rank alone
 	return CRD_OK;
@@ -559,16 +609,18 @@ int crd_rhs_device(crd_ctx *c, double t, const void *y, void *ydot)
 	if (c->halo == CRD_HALO_RCCL) {
 		// Exchange(): pack var0 of the first / last row, swap with the ring neighbours (src/FHNmodel_torus.cpp:775-950;
 		// only var0 is ever read from the strips, :548,:570).
-		const int prev = (c->slab + c->n_slabs - 1) % c->n_slabs, next = (c->slab + 1) % c->n_slabs;
 		const ncclDataType_t dt = c->p.precision == CRD_PRECISION_F64 ? ncclDouble : ncclFloat;
+		crd_halo_op ops[4];
+		if (crd_halo_plan(c->slab, c->n_slabs, c->nyl, 1, ops) != CRD_OK) return fail(c, CRD_EINVAL, "bad halo plan");
 		HIP_TRY(c, launch_aos_row_extract(c->p.precision, y, c->edge_lo, c->nx, 0, c->compute));
 		HIP_TRY(c, launch_aos_row_extract(c->p.precision, y, c->edge_hi, c->nx, c->nyl - 1, c->compute));
-		NCCL_TRY(c, ncclGroupStart());
-		NCCL_TRY(c, ncclSend(c->edge_hi, (size_t)c->nx, dt, next, c->nccl, c->compute));
-		NCCL_TRY(c, ncclSend(c->edge_lo, (size_t)c->nx, dt, prev, c->nccl, c->compute));
-		NCCL_TRY(c, ncclRecv(c->ghost_lo, (size_t)c->nx, dt, prev, c->nccl, c->compute));
-		NCCL_TRY(c, ncclRecv(c->ghost_hi, (size_t)c->nx, dt, next, c->nccl, c->compute));
-		NCCL_TRY(c, ncclGroupEnd());
+		NCCL_TRY(c, g_rccl.GroupStart());
+		for (const crd_halo_op &op : ops) {
+			// the plan's rows map onto the packed strips: row 0 / nyl-1 are edge_lo / edge_hi, row -1 / nyl the ghost strips
+			if (op.is_send) NCCL_TRY(c, g_rccl.Send(op.row_begin == 0 ? c->edge_lo : c->edge_hi, (size_t)c->nx, dt, op.peer, c->nccl, c->compute));
+			else NCCL_TRY(c, g_rccl.Recv(op.row_begin < 0 ? c->ghost_lo : c->ghost_hi, (size_t)c->nx, dt, op.peer, c->nccl, c->compute));
+		}
+		NCCL_TRY(c, g_rccl.GroupEnd());
 	}
 	HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorbing(c, t) ? 1 : 0, y, ydot, c->ghost_lo, c->ghost_hi, c->compute));
 	return CRD_OK;

@@ -137,6 +137,17 @@ int crd_slab_extents(int64_t ny, int slab, int n_slabs, int64_t *js, int64_t *je
 	return CRD_OK;
 }
 
+int crd_halo_plan(int slab, int n_slabs, int64_t nyl, int depth, crd_halo_op ops[4])
+{
+	if (!ops || n_slabs < 1 || slab < 0 || slab >= n_slabs || depth < 1 || nyl < depth) return CRD_EINVAL;
+	const int prev = (slab + n_slabs - 1) % n_slabs, next = (slab + 1) % n_slabs;
+	ops[0] = crd_halo_op{1, next, nyl - depth, depth};  // my last rows are the next slab's low ghosts
+	ops[1] = crd_halo_op{1, prev, 0, depth};            // my first rows are the previous slab's high ghosts
+	ops[2] = crd_halo_op{0, prev, -(int64_t)depth, depth};
+	ops[3] = crd_halo_op{0, next, nyl, depth};
+	return CRD_OK;
+}
+
 static double gb_residual_y(double Z, double Y)
 {
 	// v2 - v3 - kf Y of src/GoldbeterModel_torus.cpp:694-695,716

@@ -40,6 +40,13 @@ def slab_extents(ny, slab, n_slabs):
     return js.value, je.value
 
 
+def halo_plan(slab, n_slabs, nyl, depth=1):
+    """The four ordered point-to-point operations of one halo exchange: [(is_send, peer, row_begin, row_count)]."""
+    ops = (capi.HaloOp * 4)()
+    check(lib().crd_halo_plan(slab, n_slabs, nyl, depth, ops), "crd_halo_plan")
+    return [(bool(o.is_send), o.peer, o.row_begin, o.row_count) for o in ops]
+
+
 def steady_state(model, beta):
     a, b = C.c_double(), C.c_double()
     m = MODELS[model] if isinstance(model, str) else model

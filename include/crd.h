@@ -162,6 +162,21 @@ int crd_comm_attach_local(crd_ctx *const *ctxs, int n_slabs);
 int crd_comm_unique_id(void *id128);
 int crd_comm_init_rccl(crd_ctx *ctx, const void *id128);
 
+/* The ring protocol of one halo exchange, as data: the four point-to-point operations slab `slab` of `n_slabs` issues,
+ * in issue order, to fill its ghost rows [-depth, 0) and [nyl, nyl+depth) from its periodic phi neighbours (replaces the
+ * N/S half of Exchange(), src/FHNmodel_torus.cpp:775-950; the E/W half disappears because a slab spans all of theta).
+ * Rows are local indices (ghost rows are negative or >= nyl).  The order matters when both neighbours are the same
+ * rank (n_slabs <= 2): operations between one pair of ranks match in issue order, so the LAST rows are sent first and
+ * the LOW ghost rows are received first.  The RCCL transport issues exactly this plan inside one ncclGroup; the CPU
+ * tests drive it over gloo. */
+typedef struct crd_halo_op {
+	int32_t is_send;    /* 1 = send owned rows, 0 = receive into ghost rows */
+	int32_t peer;       /* slab index of the other side */
+	int64_t row_begin;  /* first local row */
+	int64_t row_count;
+} crd_halo_op;
+int crd_halo_plan(int slab, int n_slabs, int64_t nyl, int depth, crd_halo_op ops[4]);
+
 /* State transfer in the boundary layout.  host_is_f64 = 1: host buffer holds doubles whatever the device
  * precision (converted on the device); 0: host buffer holds the device precision. */
 int crd_state_upload(crd_ctx *ctx, const void *y_aos_host, int host_is_f64);

@@ -1,0 +1,135 @@
+"""The N>1 path on CPU: world_size 2 and 3 over gloo, one process per phi-slab.
+
+Each rank owns slab r of the grid (libcrd's crd_slab_extents), keeps its rows in a plane with ghost rows, and fills the
+ghosts by executing libcrd's own ring protocol (crd_halo_plan -- the exact operation list the RCCL transport issues inside
+one ncclGroup) with gloo isend / irecv.  The compute between exchanges is the CPU oracle (this is a test: the product
+computes on the GPU), so what is verified here is the decomposition, the neighbour / ordering logic -- including the
+two-rank ring where both neighbours are the same peer -- and the per-stage exchange schedule of the staged RK4 stepper.
+"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _exchange(dist, plane, nyl, depth, rank, world, crd):
+    """Run the library's halo plan on a (nyl + 2 depth, nx) host plane with gloo point-to-point operations."""
+    import torch
+
+    ops, keep = [], []
+    for is_send, peer, row_begin, row_count in crd.halo_plan(rank, world, nyl, depth):
+        view = plane[depth + row_begin: depth + row_begin + row_count]
+        if peer == rank:  # self ring (world 1) is handled by the caller
+            raise AssertionError("self peer in a multi-rank run")
+        t = torch.from_numpy(view)
+        keep.append(t)
+        ops.append(dist.P2POp(dist.isend if is_send else dist.irecv, t, peer))
+    for req in dist.batch_isend_irecv(ops):
+        req.wait()
+
+
+def _worker(rank, world, port, result_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+
+    import crdmodel_amd as crd
+    from oracle import crd_oracle as co
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        nx, L, W, D, beta, tB = 24, 80.0, 20.0, 0.12, 1.25, 0.11
+        params = crd.make_params("fhn", "torus", nx, L, W, D, beta, ny=50, vary_beta=1, beta_min=0.7, beta_max=1.7, t_boundary=tB)
+        g = crd.grid_of(params)
+        gp = co.make_problem(co.FHN, co.TORUS, nx, L, W, D, beta, ny=50, vary_beta=1, beta_min=0.7, beta_max=1.7, t_boundary=tB)
+        js, je = crd.slab_extents(g.ny, rank, world)
+        nyl = je - js + 1
+        sub = co.subproblem(gp, 1, world, 0, rank)
+        assert (sub.js, sub.je) == (js, je)
+
+        rng = np.random.default_rng(5)  # same field on every rank
+        y_global = rng.standard_normal((g.ny, nx, 2))
+
+        # --- one halo exchange, depth 1 and depth 4: ghosts must be the periodic neighbour rows ---------------------
+        for depth in (1, 4):
+            plane = np.full((nyl + 2 * depth, nx), np.nan)
+            plane[depth:depth + nyl] = y_global[js:je + 1, :, 0]
+            _exchange(dist, plane, nyl, depth, rank, world, crd)
+            rows = np.arange(js - depth, je + 1 + depth) % g.ny
+            assert np.array_equal(plane, y_global[rows, :, 0]), "ghost rows are not the periodic neighbours"
+
+        # --- f() on the slab with exchanged strips == rows of the whole-domain f() -------------------------------
+        def slab_rhs(t, y_local):
+            plane = np.empty((nyl + 2, nx))
+            plane[1:-1] = y_local[..., 0]
+            _exchange(dist, plane, nyl, 1, rank, world, crd)
+            w, e, _, _ = co.pack_edges(sub, y_local)  # theta is not split: W / E strips are the slab's own columns
+            srecv, nrecv = np.zeros(2 * nx), np.zeros(2 * nx)
+            srecv[0::2], nrecv[0::2] = plane[0], plane[-1]  # only var0 of the strips is ever read (:548,:570)
+            return co.rhs_subdomain(sub, t, y_local, w, e, srecv, nrecv)
+
+        y_loc = np.ascontiguousarray(y_global[js:je + 1])
+        for t in (0.0, 1.0):
+            assert np.array_equal(slab_rhs(t, y_loc), co.rhs(gp, t, y_global)[js:je + 1])
+
+        # --- staged RK4: one exchange per stage, three steps crossing tBoundary ---------------------------------
+        dt, nsteps = 0.05, 3
+        y = y_loc.copy()
+        for n in range(nsteps):
+            t = n * dt
+            k1 = slab_rhs(t, y)
+            k2 = slab_rhs(t + 0.5 * dt, y + (0.5 * dt) * k1)
+            k3 = slab_rhs(t + 0.5 * dt, y + (0.5 * dt) * k2)
+            k4 = slab_rhs(t + dt, y + dt * k3)
+            y = y + (dt / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        ref = co.rk4(gp, y_global, 0.0, dt, nsteps)[js:je + 1]
+        assert np.array_equal(y, ref)
+
+        # --- the aggregation bench.py does: max over ranks of the elapsed time --------------------------------
+        import torch
+
+        tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        assert tmax.item() == float(world)
+        ident = [b"x" * 128 if rank == 0 else None]
+        dist.broadcast_object_list(ident, src=0)  # how the RCCL unique id travels
+        assert ident[0] == b"x" * 128
+        open(os.path.join(result_dir, "ok.%d" % rank), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_phi_slab_ring_over_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert sorted(os.listdir(tmp_path)) == ["ok.%d" % r for r in range(world)]
+
+
+def test_halo_plan_shape():
+    import crdmodel_amd as crd
+
+    for world in (1, 2, 3, 8):
+        for slab in range(world):
+            ops = crd.halo_plan(slab, world, 100, 4)
+            sends, recvs = [o for o in ops if o[0]], [o for o in ops if not o[0]]
+            assert len(sends) == len(recvs) == 2
+            assert {o[1] for o in sends} == {(slab - 1) % world, (slab + 1) % world}
+            assert [o[2] for o in recvs] == [-4, 100] and [o[2] for o in sends] == [96, 0]
+            # the operation sent to `next` comes first, the one received from `prev` comes first: with a single peer the
+            # k-th send of one side meets the k-th receive of the other
+            assert sends[0][1] == (slab + 1) % world and recvs[0][1] == (slab - 1) % world
+    with pytest.raises(crd._capi.CrdError):
+        crd.halo_plan(0, 2, 3, 4)

@@ -1,0 +1,189 @@
+"""CPU-side checks of libcrd's C ABI: the library loads, exports every symbol include/crd.h declares, and its host-side
+helpers (geometry, slabs, stable states, initial conditions, ini reader) agree with the oracle.  No kernel is launched."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import crdmodel_amd as crd
+from conftest import GOLDEN, ROOT
+from oracle import crd_oracle as co
+
+INI = os.path.join(GOLDEN, "ini")
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "crd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(crd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = declared_functions()
+    assert len(names) >= 30
+    L = C.CDLL(crd._capi.LIB_PATH)
+    missing = [n for n in names if not hasattr(L, n)]
+    assert not missing, missing
+    # and the ctypes table binds exactly the declared set, so a header change cannot go unbound
+    assert sorted(crd._capi._SIGNATURES) == names
+    assert crd._capi.lib().crd_abi_version() == 1
+
+
+def test_status_strings():
+    L = crd._capi.lib()
+    assert L.crd_status_string(0) == b"ok"
+    assert len({L.crd_status_string(-k) for k in range(0, 8)}) == 8
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a HIP device crd_create fails with CRD_EHIP; there is no CPU path to fall back to."""
+    if os.path.exists("/dev/kfd"):
+        pytest.skip("a GPU is present")
+    p = crd.make_params("fhn", "torus", 32, 80.0, 20.0, 0.12, 1.25)
+    with pytest.raises(crd._capi.CrdError) as e:
+        crd.Slab(p)
+    assert e.value.status == crd._capi.EHIP and "no CPU fallback" in str(e.value)
+
+
+def test_geometry_matches_oracle_and_golden():
+    geo = json.load(open(os.path.join(GOLDEN, "geometry.json")))
+    for e in geo["ny"]:
+        p = crd.make_params("fhn", e["surface"], e["nx"], e["L"], e["W"], 0.12, 1.25)
+        g = crd.grid_of(p)
+        assert (g.nx, g.ny, g.dx, g.dy, g.R, g.r) == (e["nx"], e["ny"], e["dx"], e["dy"], e["R"], e["r"])
+    # phiMesh override keeps everything else
+    g = crd.grid_of(crd.make_params("fhn", "torus", 8192, 80.0, 20.0, 0.12, 1.25, ny=8192))
+    assert (g.nx, g.ny) == (8192, 8192) and g.dy == (2.0 * 3.1415926535897932) / 8191.0
+
+
+def test_bad_params_are_rejected():
+    L = crd._capi.lib()
+    g = crd._capi.Grid()
+    for kw in (dict(nx=1), dict(surface_width=0.0), dict(diffusion=float("nan")), dict(model=7), dict(precision=3)):
+        p = crd.make_params("fhn", "torus", 32, 80.0, 20.0, 0.12, 1.25)
+        for k, v in kw.items():
+            setattr(p, k, v)
+        assert L.crd_grid_from_params(C.byref(p), C.byref(g)) == crd._capi.EINVAL
+    # horn torus (R = r) needs an explicit phiMesh
+    p = crd.make_params("fhn", "torus", 32, 20.0, 20.0, 0.12, 1.25)
+    assert L.crd_grid_from_params(C.byref(p), C.byref(g)) == crd._capi.EINVAL
+
+
+def test_slab_extents_follow_setupdecomp():
+    geo = json.load(open(os.path.join(GOLDEN, "geometry.json")))
+    for e in geo["slabs"]:
+        got = [list(crd.slab_extents(e["ny"], k, e["n_slabs"])) for k in range(e["n_slabs"])]
+        assert got == e["extents"]
+        assert got[0][0] == 0 and got[-1][1] == e["ny"] - 1
+        assert all(got[k][1] + 1 == got[k + 1][0] for k in range(len(got) - 1))  # contiguous cover
+    with pytest.raises(crd._capi.CrdError):
+        crd.slab_extents(100, 4, 4)
+
+
+def test_steady_states():
+    geo = json.load(open(os.path.join(GOLDEN, "geometry.json")))
+    for e in geo["steady"]:
+        got = crd.steady_state(e["model"], e["beta"])
+        assert got == pytest.approx(tuple(e["state"]), rel=1e-14)
+    assert crd.steady_state("fhn", 1.25) == (-1.25, 1.25 ** 3 - 3 * 1.25)
+    # beta = 0.4 -> (0.392, 1.64562146714406)
+    assert crd.steady_state("goldbeter", 0.4) == pytest.approx((0.392, 1.64562146714406), rel=1e-14)
+
+
+IC_CASES = [
+    ("fhn", "torus", dict(wave_inside=0), {}),
+    ("fhn", "torus", dict(wave_inside=1), {}),
+    ("fhn", "torus", dict(wave_inside=0), dict(vary_beta=1, beta_min=0.7, beta_max=1.7)),
+    ("fhn", "flat", {}, {}),
+    ("fhn", "flat", {}, dict(vary_beta=1, beta_min=0.7, beta_max=1.7)),
+    ("goldbeter", "torus", dict(wave_inside=1, wave_length=0.2), {}),
+    ("goldbeter", "torus", dict(wave_inside=0, wave_length=0.2), {}),
+    ("goldbeter", "flat", dict(wave_length=0.2), {}),
+    ("goldbeter", "flat", dict(wave_length=0.2, ic_type=0), dict(vary_beta=1, beta_max=1.0)),
+    ("goldbeter", "flat", dict(wave_length=0.2, ic_type=1), dict(vary_beta=1, beta_max=1.0)),
+    ("goldbeter", "flat", dict(wave_length=0.2, ic_type=2), dict(vary_beta=1, beta_max=1.0)),
+    ("goldbeter", "torus", dict(wave_inside=0, wave_length=0.2, ic_type=1), dict(vary_beta=1)),
+]
+
+
+@pytest.mark.parametrize("model,surface,ickw,pkw", IC_CASES)
+def test_initial_conditions_match_oracle(model, surface, ickw, pkw):
+    """The four programs' IC rules (rectangle inside / outside, Goldbeter icType 0/1/2 incl. the unseeded rand())."""
+    beta = 1.25 if model == "fhn" else 0.4
+    p = crd.make_params(model, surface, 40, 80.0, 20.0, 0.12, beta, **pkw)
+    kw = dict(wave_length=0.1, wave_width=0.5)
+    kw.update(ickw)
+    cfg = crd.run_config(p, **kw)
+    y = crd.initial_conditions(cfg)
+    op = co.make_problem({"fhn": co.FHN, "goldbeter": co.GOLDBETER}[model], {"torus": co.TORUS, "flat": co.FLAT}[surface], 40, 80.0, 20.0,
+                         0.12, beta, **pkw)
+    ref = co.initial_conditions(op, kw["wave_length"], kw["wave_width"], kw.get("wave_inside", 0), kw.get("ic_type", 0),
+                                crd.steady_state(model, beta))
+    assert y.shape == ref.shape == (op.ny, op.nx, 2)
+    assert np.array_equal(y, ref)
+    if not pkw.get("vary_beta") or kw.get("ic_type") == 1:
+        frac = np.mean(y[..., 0] != y[0, 0, 0]) if not (surface == "torus" and kw.get("wave_inside", 0) == 0 and kw.get("ic_type") == 1) else 0.05
+        assert 0.0 < frac < 0.2  # a perturbed rectangle exists and is small
+    # slab-wise generation == rows of the whole-domain field (except rand(), which restarts per slab like per MPI rank)
+    if kw.get("ic_type") != 2:
+        js, je = crd.slab_extents(op.ny, 1, 3)
+        assert np.array_equal(crd.initial_conditions(cfg, js, je), ref[js:je + 1])
+
+
+def test_ini_shipped_parameter_sets():
+    fhn = crd.load_ini(os.path.join(INI, "fhn_shipped.ini"), "fhn", "torus")  # carries xMesh: accepted for the FHN programs too
+    p = fhn.params
+    assert (p.nx, p.diffusion, p.beta, p.surface_width, p.surface_length) == (400, 0.12, 1.25, 20.0, 80.0)
+    assert (p.vary_beta, p.beta_min, p.beta_max, p.t_boundary) == (1, 0.7, 1.7, 38.0)
+    assert (fhn.wave_length, fhn.wave_width, fhn.wave_inside, fhn.output_timestep, fhn.t_final, fhn.include_all_vars) == (0.1, 0.5, 0, 20, 50.0, 0)
+    assert crd.grid_of(p).ny == 1600
+    assert (fhn.dt, fhn.n_gpus, fhn.stepper, p.precision) == (0.0, 1, 0, 0)
+
+    gb_t = crd.load_ini(os.path.join(INI, "goldbeter_shipped.ini"), "goldbeter", "torus")
+    gb_f = crd.load_ini(os.path.join(INI, "goldbeter_shipped.ini"), "goldbeter", "flat")
+    assert (gb_t.params.nx, gb_t.params.beta, gb_t.wave_inside, gb_t.output_timestep) == (100, 0.4, 1, 5)
+    # Goldbeter torus never reads betaMin / betaMax / icType (they stay 0); Goldbeter flat does
+    assert (gb_t.params.beta_max, gb_t.ic_type) == (0.0, 0) and (gb_f.params.beta_max, gb_f.ic_type) == (1.0, 2)
+    assert crd.grid_of(gb_f.params).ny == 400
+
+
+def test_ini_missing_and_malformed_keys(tmp_path):
+    # data/temp.ini has thetaMesh but no betaMin/betaMax while varyBeta = 1: the FHN programs abort on it, so do we
+    with pytest.raises(crd._capi.CrdError) as e:
+        crd.load_ini(os.path.join(INI, "temp_shipped.ini"), "fhn", "torus")
+    assert e.value.status == crd._capi.EPARSE and "betaMin" in str(e.value)
+    t = crd.load_ini(os.path.join(INI, "temp_shipped.ini"), "goldbeter", "torus")  # reads thetaMesh in place of xMesh
+    assert t.params.nx == 200 and t.params.vary_beta == 1
+
+    good = open(os.path.join(INI, "small_run.ini")).read()
+    cases = {
+        "no_key": (good.replace("diffusion = 0.12\n", ""), crd._capi.EPARSE, "diffusion"),
+        "not_a_number": (good.replace("beta = 1.25", "beta = 1.25x"), crd._capi.EPARSE, "conversion"),
+        "duplicate": (good.replace("beta = 1.25\n", "beta = 1.25\nbeta = 2\n"), crd._capi.EPARSE, "duplicate"),
+        "no_equals": (good.replace("beta = 1.25", "beta 1.25"), crd._capi.EPARSE, "'='"),
+        "bad_section": (good.replace("[System]", "[System"), crd._capi.EPARSE, "unmatched"),
+        "no_system": (good.replace("varyBeta = 0\n", ""), crd._capi.EPARSE, "varyBeta"),
+        "bad_value": (good.replace("thetaMesh = 16", "thetaMesh = 1"), crd._capi.EINVAL, "nx"),
+    }
+    for name, (text, status, needle) in cases.items():
+        f = tmp_path / (name + ".ini")
+        f.write_text(text)
+        with pytest.raises(crd._capi.CrdError) as e:
+            crd.load_ini(f, "fhn", "torus")
+        assert e.value.status == status and needle in str(e.value), (name, str(e.value))
+    with pytest.raises(crd._capi.CrdError) as e:
+        crd.load_ini(tmp_path / "absent.ini", "fhn", "torus")
+    assert e.value.status == crd._capi.EIO
+
+    small = crd.load_ini(os.path.join(INI, "small_run.ini"), "fhn", "torus")
+    assert (small.params.nx, small.params.ny, small.dt, small.include_all_vars) == (16, 40, 0.02, 1)
+
+
+def test_stable_dt_bounds_the_diffusion_limit():
+    """SURVEY 8d quotes 1.25e-4 (4096^2) and 3.1e-5 (8192^2) as RK4 limits of the diffusion operator alone."""
+    for n, lim in ((4096, 1.25e-4), (8192, 3.1e-5)):
+        dt = crd.stable_dt(crd.make_params("fhn", "torus", n, 80.0, 20.0, 0.12, 1.25, ny=n))
+        assert 0.8 * lim < dt <= 1.02 * lim

@@ -1,0 +1,174 @@
+"""The oracle checks itself: C restatement vs golden vectors, vs the independent numpy restatement, vs analytic
+known answers the reference's code implies, and decomposition invariance (what MPI delivers at np in {1,2,4}).
+
+PARITY UNPINNED against reference-run output (the reference cannot be built here; it ships no tests or fixtures)."""
+import numpy as np
+import pytest
+
+from conftest import golden_names, load_golden, oracle_problem, rel_err
+from oracle import crd_oracle as co
+from oracle import crd_oracle_np as cn
+
+
+def np_kwargs(meta):
+    return dict(beta=meta["beta"], vary_beta=meta["vary_beta"], beta_min=meta["beta_min"], beta_max=meta["beta_max"],
+                t_boundary=meta["t_boundary"], just_diffusion=meta["just_diffusion"])
+
+
+@pytest.mark.parametrize("name", golden_names("rhs_"))
+def test_c_oracle_reproduces_golden_rhs(name):
+    meta, arr = load_golden(name)
+    p = oracle_problem(meta)
+    assert (p.nx, p.ny) == (meta["nx"], meta["ny"])
+    assert np.array_equal(co.rhs(p, meta["t_absorbing"], arr["y"]), arr["ydot_absorbing"])
+    assert np.array_equal(co.rhs(p, meta["t_free"], arr["y"]), arr["ydot_free"])
+    assert np.array_equal(co.rhs(p, meta["t_free"], arr["y"], nthreads=3), arr["ydot_free"])  # OpenMP split changes nothing
+
+
+@pytest.mark.parametrize("name", golden_names("rhs_"))
+def test_numpy_restatement_agrees(name):
+    """Two independently written restatements (C loops with halo strips; numpy with np.roll) agree to round-off."""
+    meta, arr = load_golden(name)
+    g = cn.geometry(meta["surface"], meta["surface_length"], meta["surface_width"], meta["nx"], meta["ny_override"])
+    assert g["ny"] == meta["ny"]
+    for key, t in (("ydot_absorbing", meta["t_absorbing"]), ("ydot_free", meta["t_free"])):
+        du, dv = cn.rhs(meta["model"], meta["surface"], g, meta["diffusion"], t, arr["y"][..., 0], arr["y"][..., 1], **np_kwargs(meta))
+        assert rel_err(du, arr[key][..., 0]) <= 2e-15
+        assert rel_err(dv, arr[key][..., 1]) <= 2e-15
+
+
+@pytest.mark.parametrize("name", golden_names("rk4_"))
+def test_rk4_golden_and_numpy(name):
+    meta, arr = load_golden(name)
+    p = oracle_problem(meta)
+    n = meta["snapshots"][0]
+    y = co.rk4(p, arr["y0"], 0.0, meta["dt"], n)
+    assert np.array_equal(y, arr["y_%d" % n])
+    g = cn.geometry(meta["surface"], meta["surface_length"], meta["surface_width"], meta["nx"], meta["ny_override"])
+    short = min(n, 20)
+    u, v = cn.rk4(meta["model"], meta["surface"], g, meta["diffusion"], arr["y0"][..., 0], arr["y0"][..., 1], 0.0, meta["dt"], short, **np_kwargs(meta))
+    yc = co.rk4(p, arr["y0"], 0.0, meta["dt"], short)
+    assert rel_err(u, yc[..., 0]) <= 1e-13 and rel_err(v, yc[..., 1]) <= 1e-13
+
+
+@pytest.mark.parametrize("dims", [(1, 1), (2, 1), (1, 2), (2, 2), (1, 4), (1, 8), (3, 2)])
+@pytest.mark.parametrize("name", ["rhs_fhn_torus_ragged", "rhs_goldbeter_flat"])
+def test_decomposition_invariance(name, dims):
+    """f through a d0 x d1 block decomposition with periodic halos == f on one block, bit for bit; (2,2) is the reference's
+    own `mpirun -np 4` layout, (1,G) the phi-slab layout of the GPU build."""
+    meta, arr = load_golden(name)
+    p = oracle_problem(meta)
+    assert np.array_equal(co.rhs(p, meta["t_absorbing"], arr["y"], *dims), arr["ydot_absorbing"])
+
+
+def test_exchange_strips_are_the_periodic_neighbours():
+    """Exchange() on one rank: the W strip is the subdomain's own last column, the S strip its last row (:854-900)."""
+    meta, arr = load_golden("rhs_fhn_torus_ragged")
+    p = oracle_problem(meta)
+    w, e, s, n = co.pack_edges(p, arr["y"])
+    assert np.array_equal(w.reshape(-1, 2), arr["y"][:, -1, :]) and np.array_equal(e.reshape(-1, 2), arr["y"][:, 0, :])
+    assert np.array_equal(s.reshape(-1, 2), arr["y"][-1, :, :]) and np.array_equal(n.reshape(-1, 2), arr["y"][0, :, :])
+    assert np.array_equal(co.rhs_subdomain(p, 50.0, arr["y"], w, e, s, n), arr["ydot_free"])
+
+
+# ---- analytic known answers ---------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("surface,L,W", [("torus", 80.0, 20.0), ("torus", 40.0, 20.0), ("flat", 80.0, 20.0)])
+@pytest.mark.parametrize("beta", [0.7, 1.25])
+def test_fhn_stable_state_is_a_fixed_point(surface, L, W, beta):
+    """Us = -beta, Vs = beta^3 - 3 beta (src/FHNmodel_torus.cpp:242-244): a uniform field at the stable state has f = 0."""
+    p = co.make_problem(co.FHN, {"torus": co.TORUS, "flat": co.FLAT}[surface], 24, L, W, 0.12, beta)
+    us, vs = co.fhn_steady(beta)
+    y = np.empty((p.ny, p.nx, 2))
+    y[..., 0], y[..., 1] = us, vs
+    assert np.max(np.abs(co.rhs(p, 0.0, y))) <= 1e-13
+
+
+@pytest.mark.parametrize("beta", [0.14, 0.4, 0.6, 1.0])
+def test_goldbeter_fixed_point(beta):
+    zs, ys = co.goldbeter_steady(beta)
+    assert zs == pytest.approx((1.0 + 7.3 * beta) / 10.0, rel=1e-15)
+    zn, yn = cn.goldbeter_steady(beta)
+    assert (zs, ys) == pytest.approx((zn, yn), rel=1e-13)
+    p = co.make_problem(co.GOLDBETER, co.TORUS, 16, 40.0, 20.0, 0.12, beta)
+    y = np.empty((p.ny, p.nx, 2))
+    y[..., 0], y[..., 1] = zs, ys
+    assert np.max(np.abs(co.rhs(p, 0.0, y))) <= 2e-12
+
+
+@pytest.mark.parametrize("m", [1, 3])
+def test_flat_laplacian_eigenfunction(m):
+    """cos(2 pi m i / nx) is an exact eigenvector of the periodic second difference: udot = cu1 (2 cos(2 pi m/nx) - 2) u
+    (src/FHNmodel_flat.cpp:489-500, index -1 wrapping to nx-1)."""
+    nx = 32
+    p = co.make_problem(co.GOLDBETER, co.FLAT, nx, 20.0, 20.0, 0.12, 0.4, just_diffusion=1)
+    i = np.arange(nx)
+    u = np.broadcast_to(np.cos(2 * np.pi * m * i / nx), (p.ny, nx))
+    y = np.stack([u, np.ones_like(u)], axis=-1).copy()
+    lam = 0.12 / p.dx / p.dx * (2 * np.cos(2 * np.pi * m / nx) - 2)
+    ydot = co.rhs(p, 0.0, y)
+    assert rel_err(ydot[..., 0], lam * u) <= 1e-13
+    assert np.all(ydot[..., 1] == 0.0)
+
+
+def test_torus_phi_eigenfunction():
+    """For u = cos(2 pi m j / ny) (theta-independent) only the phi term survives:
+    udot = D / (R + r cos theta_i)^2 / dy^2 * (2 cos(2 pi m / ny) - 2) u  (src/FHNmodel_torus.cpp:537)."""
+    p = co.make_problem(co.GOLDBETER, co.TORUS, 20, 80.0, 20.0, 0.12, 0.4, just_diffusion=1)
+    m = 2
+    j = np.arange(p.ny)
+    u = np.broadcast_to(np.cos(2 * np.pi * m * j / p.ny)[:, None], (p.ny, p.nx))
+    y = np.stack([u, np.zeros_like(u)], axis=-1).copy()
+    theta = np.arange(p.nx) * p.dx
+    expect = 0.12 / (p.R + p.r * np.cos(theta)) ** 2 / p.dy ** 2 * (2 * np.cos(2 * np.pi * m / p.ny) - 2) * u
+    assert rel_err(co.rhs(p, 0.0, y)[..., 0], expect) <= 1e-13
+
+
+def test_torus_theta_operator_is_the_curvilinear_laplacian():
+    """The theta part is (1/r^2) u_tt - sin t / (r (R + r cos t)) u_t: second-order accurate on a smooth periodic field."""
+    errs = []
+    for nx in (64, 128):
+        p = co.make_problem(co.GOLDBETER, co.TORUS, nx, 80.0, 20.0, 1.0, 0.4, ny=8, just_diffusion=1)
+        # sample on the periodic points the stencil actually couples: theta_i = i dx with dx = 2 pi/(nx-1) wraps with a
+        # duplicated seam, so use a field that is smooth in INDEX space: k = 2 pi i / nx
+        i = np.arange(nx)
+        k = 2 * np.pi * i / nx
+        u = np.broadcast_to(np.sin(k), (p.ny, nx))
+        y = np.stack([u, np.zeros_like(u)], axis=-1).copy()
+        got = co.rhs(p, 0.0, y)[0, :, 0]
+        theta = i * p.dx
+        s = 2 * np.pi / nx / p.dx  # d k / d theta
+        exact = (1 / p.r ** 2) * (-s * s * np.sin(k)) + (-np.sin(theta) / (p.r * (p.R + p.r * np.cos(theta)))) * (s * np.cos(k))
+        errs.append(np.max(np.abs(got - exact)))
+    assert errs[1] < errs[0] / 3.5  # ~4x per mesh doubling
+
+
+def test_absorbing_rows_rule():
+    """Rows j = 0 and j = ny-1 get f = 0 for both variables only while t < tBoundary (strict), :643-653."""
+    meta, arr = load_golden("rhs_fhn_torus")
+    p = oracle_problem(meta)
+    tb = meta["t_boundary"]
+    before, at = co.rhs(p, np.nextafter(tb, 0.0), arr["y"]), co.rhs(p, tb, arr["y"])
+    assert np.all(before[0] == 0) and np.all(before[-1] == 0) and np.any(before[1] != 0)
+    assert np.array_equal(at, arr["ydot_free"]) and np.any(at[0] != 0)
+    assert np.array_equal(before[1:-1], at[1:-1])  # the neighbours still read the boundary rows normally
+
+
+def test_goldbeter_just_diffusion_skips_absorbing_rows():
+    meta, arr = load_golden("rhs_goldbeter_torus_justdiffusion")
+    assert np.array_equal(arr["ydot_absorbing"], arr["ydot_free"])
+    assert np.all(arr["ydot_free"][..., 1] == 0.0)
+
+
+def test_ny_truncation_table():
+    """ny = (long)(NX * (R / r)) truncates (src/FHNmodel_torus.cpp:193): L=100, W=20, nx=100 gives 499, not 500."""
+    import json, os
+    from conftest import GOLDEN
+
+    geo = json.load(open(os.path.join(GOLDEN, "geometry.json")))
+    by = {(e["surface"], e["L"], e["W"], e["nx"]): e["ny"] for e in geo["ny"]}
+    assert by[("torus", 100.0, 20.0, 100)] == 499 and by[("torus", 100.0, 20.0, 400)] == 1999
+    assert by[("torus", 80.0, 20.0, 400)] == 1600 and by[("flat", 90.0, 20.0, 100)] == 400
+    for e in geo["ny"]:
+        g = cn.geometry(e["surface"], e["L"], e["W"], e["nx"])
+        assert (g["ny"], g["dx"], g["dy"]) == (e["ny"], e["dx"], e["dy"])
