@@ -1,0 +1,51 @@
+"""End to end on the GPU: `<program> <ini>` (the reference's command line) -> per-subdomain text files -> the plot
+script's loader logic -> compared with the oracle's trajectory at the output times."""
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+import crdmodel_amd as crd
+from conftest import GOLDEN, ROOT, rel_err
+from oracle import crd_oracle as co
+from test_io_formats import load_like_the_plot_script
+
+pytestmark = pytest.mark.gpu
+INI = os.path.join(GOLDEN, "ini", "small_run.ini")
+BIN = os.path.join(ROOT, "crdmodel_amd", "bin")
+
+
+def oracle_outputs(cfg):
+    p = cfg.params
+    g = crd.grid_of(p)
+    op = co.make_problem(co.FHN, co.TORUS, g.nx, p.surface_length, p.surface_width, p.diffusion, p.beta, ny=p.ny, t_boundary=p.t_boundary)
+    y = co.initial_conditions(op, cfg.wave_length, cfg.wave_width, cfg.wave_inside, 0)
+    frames = [y]
+    d_tout = cfg.t_final / cfg.output_timestep
+    steps = int(np.ceil(d_tout / cfg.dt - 1e-12))
+    dt = d_tout / steps
+    for k in range(cfg.output_timestep):
+        y = co.rk4(op, y, k * d_tout, dt, steps)
+        frames.append(y)
+    return np.stack(frames)
+
+
+@pytest.mark.parametrize("argv", [["FHNmodel_torus"], ["crd_run", "--model", "fhn", "--surface", "torus", "--gpus", "3", "--devices", "1", "--quiet"]])
+def test_driver_writes_reference_format(gpu_device, tmp_path, argv):
+    cfg = crd.load_ini(INI, "fhn", "torus")
+    exe = os.path.join(BIN, argv[0])
+    r = subprocess.run([exe] + argv[1:] + [INI], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    if "--quiet" not in argv:
+        assert "2D FHN model PDE problem on a torus:" in r.stdout and "nx = 16" in r.stdout and "ny = 40" in r.stdout
+        assert "100 %" in r.stdout
+    want = oracle_outputs(cfg)
+    u, meta = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "u")
+    v, _ = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "v")  # includeAllVars = 1 in this ini
+    assert meta["nprocs"] == (3 if "--gpus" in argv else 1)
+    assert u.shape == want[..., 0].shape == (cfg.output_timestep + 1, 40, 16)
+    assert np.array_equal(u[0], want[0, ..., 0]) and np.array_equal(v[0], want[0, ..., 1])  # IC row is exact
+    assert rel_err(u, want[..., 0]) <= 1e-9 and rel_err(v, want[..., 1]) <= 1e-9
+    assert np.abs(u[-1] - u[0]).max() > 0.1  # the wave actually moved
