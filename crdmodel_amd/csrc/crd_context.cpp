@@ -479,6 +479,8 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	d.wrap = (n_slabs == 1);
 	d.has_row0 = (c->js == 0);
 	d.has_rowN = (c->je == c->g.ny - 1);
+	d.js = (int)c->js;
+	d.ny = (int)c->g.ny;
 	d.model = p->model;
 	d.just_diffusion = (p->model == CRD_MODEL_GOLDBETER && p->just_diffusion != 0);
 	if (hipStreamSynchronize(c->compute) != hipSuccess) return bail(fail(c, CRD_EHIP, "device initialisation failed"));

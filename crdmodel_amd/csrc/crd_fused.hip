@@ -1,14 +1,287 @@
-// crd_fused.hip -- whole-RK4-step kernel (all four stages on chip).  Placeholder until the kernel lands: the
-// context falls back to the staged stepper while fused_step_supported() is false.
+// crd_fused.hip -- one classical RK4 step of the whole slab in ONE kernel launch: all four RHS evaluations and the
+// stage updates happen on chip, so a grid-point-step costs one read and one write of the state (32 B in fp64) instead
+// of the 256 B the four stage kernels of crd_kernels.hip move.  Same arithmetic per point as the staged stepper.
+//
+// Structure (no LDS, no barriers, no MFMA): every WAVEFRONT is an independent work item.  It owns a strip of 64
+// consecutive theta columns -- one column per lane, 56 valid outputs in the middle and a 4-column apron on each side
+// that is recomputed redundantly -- and marches along phi through a chunk of rows as a 4-deep software pipeline:
+//   iteration m:  load row p        (state y0, prefetched one iteration ahead)
+//                 stage 1 on row p-1 (needs y0 rows p-2..p)          -> y1 row p-1, acc row p-1
+//                 stage 2 on row p-2 (needs y1 rows p-3..p-1)        -> y2 row p-2
+//                 stage 3 on row p-3 (needs y2 rows p-4..p-2)        -> y3 row p-3
+//                 stage 4 on row p-4 (needs y3 rows p-5..p-3)        -> new state row p-4, stored
+// The phi neighbours of a row are the lane's own registers from neighbouring iterations; the theta neighbours are the
+// adjacent lanes' registers, fetched with DPP wavefront shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1).  Each stage
+// invalidates one more apron column per side, hence 4 + 4 of 64; chunks start 4 rows early and end 4 rows late for the
+// same reason in phi (rows come from the slab's ghost rows, or wrap for a single slab).
 #include <hip/hip_runtime.h>
 
-#include "crd_internal.h"
-#include "crd_kernels.h"
+#include <type_traits>
+
+#include "crd_device.h"
 
 namespace crd {
 
-bool fused_step_supported(int, const SlabDesc &) { return false; }
+namespace {
+
+using namespace dev;
+
+constexpr int kApron = 4;                    // RK4 stages = halo depth
+constexpr int kLanes = 64;
+constexpr int kValid = kLanes - 2 * kApron;  // 56 output columns per wavefront
+constexpr int kWavesPerBlock = 4;
+constexpr int kPrefetch = 4;                 // rows in flight per wavefront; equals the unroll factor so slots stay static
+
+// Value held by lane-1 / lane+1 of this wavefront (edge lanes get their own value back: apron garbage by design).
+template <typename Real>
+__device__ __forceinline__ Real from_lane_below(Real x);
+template <typename Real>
+__device__ __forceinline__ Real from_lane_above(Real x);
+
+template <>
+__device__ __forceinline__ double from_lane_below<double>(double x)
+{
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ double from_lane_above<double>(double x)
+{
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+template <>
+__device__ __forceinline__ float from_lane_below<float>(float x)
+{
+	const int v = __float_as_int(x);
+	return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false));
+}
+template <>
+__device__ __forceinline__ float from_lane_above<float>(float x)
+{
+	const int v = __float_as_int(x);
+	return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false));
+}
+
+// A value known to be identical in every lane, moved to scalar registers.
+__device__ __forceinline__ double uniform(double x)
+{
+	return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ float uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+template <typename Real>
+struct FusedArgs {
+	const Real *in_u, *in_v;  // y0, pointers to local row 0 (ghost rows at negative offsets)
+	Real *out_u, *out_v;      // new state, local row 0
+	Real h2, h3, h6, h1;      // dt/2, dt/3, dt/6, dt
+	int absorb[4];            // t_stage < tBoundary for the four stages
+	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
+	int row_begin, row_end;   // rows of the slab this launch produces
+	int chunk;                // rows per work item
+	int nstrips, nitems;
+};
+
+template <typename Real, int MODEL>
+__global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
+{
+	const int lane = threadIdx.x & (kLanes - 1);
+	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
+	// per-row table reads, the boundary-row tests) in scalar registers.
+	const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
+	if (item >= a.nitems) return;
+	// consecutive items walk theta first: the four wavefronts of a block read adjacent, overlapping strips
+	const int strip = item % a.nstrips, chunk = item / a.nstrips;
+	const int nx = s.nx;
+
+	int x = strip * kValid - kApron + lane;  // this lane's column, wrapped periodically (nx may be smaller than 64)
+	x %= nx;
+	if (x < 0) x += nx;
+	const int out_col = strip * kValid + (lane - kApron);
+	const bool lane_stores = lane >= kApron && lane < kLanes - kApron && out_col < nx;
+
+	const int j0 = a.row_begin + chunk * a.chunk;
+	const int j1 = (j0 + a.chunk < a.row_end) ? j0 + a.chunk : a.row_end;
+	const int jbase = j0 - kApron;
+	const int niter = (j1 - j0) + 2 * kApron;  // >= 9
+	const int jlast = j1 + kApron - 1;         // last row the pipeline consumes
+
+	const Real cA = s.cA[x], cP = s.cP[x], cX = s.cX, ka4 = s.ka4;
+	const bool jd = s.just_diffusion != 0;
+
+	// Row base pointers are scalar; a single slab wraps rows outside [0, nyl).
+	auto row_base = [&](int j) -> ptrdiff_t {
+		if (s.wrap) {
+			if (j < 0) j += s.nyl;
+			else if (j >= s.nyl) j -= s.nyl;
+		}
+		return (ptrdiff_t)j * nx;
+	};
+	// Global phi boundary rows (src/FHNmodel_torus.cpp:643-653), also when they are recomputed as another slab's ghost rows.
+	auto boundary_row = [&](int j) -> bool {
+		int gj = a.js + j;
+		if (gj < 0) gj += a.ny;
+		else if (gj >= a.ny) gj -= a.ny;
+		return gj == 0 || gj == a.ny - 1;
+	};
+
+	// Pipeline registers.  Row jbase+m of an array lives in slot m & 3 (m & 1 for the two-deep v arrays), so with the
+	// loop unrolled four times every access has a compile-time slot and no value is ever moved between registers.
+	Real u0[4], v0[4], U1[4], U2[4], U3[4], V1[2], V2[2], V3[2], aU[4], aV[4];
+#pragma unroll
+	for (int k = 0; k < 4; k++) u0[k] = v0[k] = U1[k] = U2[k] = U3[k] = aU[k] = aV[k] = (Real)0;
+	V1[0] = V1[1] = V2[0] = V2[1] = V3[0] = V3[1] = (Real)0;
+
+	// Rows are fetched kPrefetch iterations before they enter the pipeline: with ~16 wavefronts per CU one row in flight
+	// per wavefront is far too little to cover HBM latency (Little's law), four rows (8 loads, 4 KiB per wavefront) is enough.
+	// The per-row reaction parameter b(j) rides along: a plain `s.brow[c]` at the point of use is a VECTOR load whose
+	// full latency the stage then waits for (four exposed L2 round trips per iteration, 60 % of the wave's lifetime when
+	// measured); fetched with the row and moved to scalar registers on arrival it costs nothing.
+	Real pu[kPrefetch], pv[kPrefetch], pb[kPrefetch], bq[4];
+#pragma unroll
+	for (int k = 0; k < kPrefetch; k++) {
+		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
+		const ptrdiff_t rb = row_base(jr);
+		pu[k] = a.in_u[rb + x];
+		pv[k] = a.in_v[rb + x];
+		pb[k] = s.brow[jr];
+		bq[k] = (Real)0;
+	}
+
+	// One pipeline iteration at m == K (mod 4).  GUARDED: the first 8 iterations of a chunk, where stage k's inputs exist
+	// only from iteration 2k on.
+	auto iteration = [&](int m, auto kk, auto guarded) {
+		constexpr int K = decltype(kk)::value;
+		constexpr bool GUARDED = decltype(guarded)::value;
+		constexpr int S0 = K & 3, S1 = (K + 3) & 3, S2 = (K + 2) & 3, S3 = (K + 1) & 3;  // slots of rows p, p-1, p-2, p-3
+		constexpr int S4 = K & 3;                                                          // row p-4 shares slot with p
+		const int p = jbase + m;
+		const Real b4 = bq[S4];  // b of row p-4 (stage 4), read before row p takes over the slot
+		u0[S0] = pu[K];
+		v0[S0] = pv[K];
+		bq[S0] = uniform(pb[K]);
+		{
+			const int pn = (p + kPrefetch < jlast) ? p + kPrefetch : jlast;  // the tail re-reads a valid row instead of running past the plane
+			const ptrdiff_t rb = row_base(pn);
+			pu[K] = a.in_u[rb + x];
+			pv[K] = a.in_v[rb + x];
+			pb[K] = s.brow[pn];
+		}
+		Real du, dv;
+		// ---- stage 1, centre row p-1: y0 rows p-2, p-1, p -----------------------------------------------------
+		if (!GUARDED || m >= 2) {
+			const int c = p - 1;
+			rhs_point<Real, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
+			                       a.absorb[0] && boundary_row(c), jd, du, dv);
+			U1[S1] = u0[S1] + a.h2 * du;
+			V1[S1 & 1] = v0[S1] + a.h2 * dv;
+			aU[S1] = u0[S1] + a.h6 * du;
+			aV[S1] = v0[S1] + a.h6 * dv;
+		}
+		// ---- stage 2, centre row p-2: y1 rows p-3, p-2, p-1 ---------------------------------------------------
+		if (!GUARDED || m >= 4) {
+			const int c = p - 2;
+			rhs_point<Real, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[S2 & 1], cA, cX, cP, bq[S2], ka4,
+			                       a.absorb[1] && boundary_row(c), jd, du, dv);
+			U2[S2] = u0[S2] + a.h2 * du;
+			V2[S2 & 1] = v0[S2] + a.h2 * dv;
+			aU[S2] += a.h3 * du;
+			aV[S2] += a.h3 * dv;
+		}
+		// ---- stage 3, centre row p-3: y2 rows p-4, p-3, p-2 ---------------------------------------------------
+		if (!GUARDED || m >= 6) {
+			const int c = p - 3;
+			rhs_point<Real, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[S3 & 1], cA, cX, cP, bq[S3], ka4,
+			                       a.absorb[2] && boundary_row(c), jd, du, dv);
+			// y3 row p-3 replaces y3 row p-7 in its slot; rows p-5 and p-4 (slots S1, S4) are still needed by stage 4 below
+			const Real y3u = u0[S3] + a.h1 * du;
+			V3[S3 & 1] = v0[S3] + a.h1 * dv;
+			aU[S3] += a.h3 * du;
+			aV[S3] += a.h3 * dv;
+			U3[S3] = y3u;
+		}
+		// ---- stage 4, centre row p-4: y3 rows p-5, p-4, p-3 -> the new state ----------------------------------
+		if (!GUARDED || m >= 8) {
+			const int c = p - 4;
+			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S1], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
+			                       a.absorb[3] && boundary_row(c), jd, du, dv);
+			if (c < j1 && lane_stores) {  // c >= j0 holds from iteration 8 on
+				const ptrdiff_t o = (ptrdiff_t)c * nx + out_col;
+				a.out_u[o] = aU[S4] + a.h6 * du;
+				a.out_v[o] = aV[S4] + a.h6 * dv;
+			}
+		}
+	};
+	using std::integral_constant;
+	iteration(0, integral_constant<int, 0>{}, std::true_type{});
+	iteration(1, integral_constant<int, 1>{}, std::true_type{});
+	iteration(2, integral_constant<int, 2>{}, std::true_type{});
+	iteration(3, integral_constant<int, 3>{}, std::true_type{});
+	iteration(4, integral_constant<int, 0>{}, std::true_type{});
+	iteration(5, integral_constant<int, 1>{}, std::true_type{});
+	iteration(6, integral_constant<int, 2>{}, std::true_type{});
+	iteration(7, integral_constant<int, 3>{}, std::true_type{});
+	int m = 2 * kApron;
+	for (; m + 3 < niter; m += 4) {
+		iteration(m, integral_constant<int, 0>{}, std::false_type{});
+		iteration(m + 1, integral_constant<int, 1>{}, std::false_type{});
+		iteration(m + 2, integral_constant<int, 2>{}, std::false_type{});
+		iteration(m + 3, integral_constant<int, 3>{}, std::false_type{});
+	}
+	if (m < niter) iteration(m, integral_constant<int, 0>{}, std::false_type{});
+	if (m + 1 < niter) iteration(m + 1, integral_constant<int, 1>{}, std::false_type{});
+	if (m + 2 < niter) iteration(m + 2, integral_constant<int, 2>{}, std::false_type{});
+}
+
+template <typename Real, int MODEL>
+hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int js, int ny, hipStream_t st)
+{
+	if (row_end <= row_begin) return hipSuccess;
+	const Slab<Real> s = typed<Real>(d);
+	FusedArgs<Real> a;
+	a.in_u = row0<Real>(c.y0.u, d.nx);
+	a.in_v = row0<Real>(c.y0.v, d.nx);
+	a.out_u = row0<Real>(c.yout.u, d.nx);
+	a.out_v = row0<Real>(c.yout.v, d.nx);
+	a.h2 = (Real)(0.5 * c.dt);
+	a.h3 = (Real)(c.dt / 3.0);
+	a.h6 = (Real)(c.dt / 6.0);
+	a.h1 = (Real)c.dt;
+	for (int k = 0; k < 4; k++) a.absorb[k] = c.absorb[k];
+	a.js = js;
+	a.ny = ny;
+	a.row_begin = row_begin;
+	a.row_end = row_end;
+	a.nstrips = (d.nx + kValid - 1) / kValid;
+	// Rows per work item: long enough to amortise the 8 apron rows, short enough to give every SIMD several items.
+	const int rows = row_end - row_begin;
+	int chunk = 128;
+	while (chunk > 16 && (long)a.nstrips * ((rows + chunk - 1) / chunk) < 256L * 4 * 6) chunk /= 2;
+	a.chunk = chunk;
+	a.nitems = a.nstrips * ((rows + chunk - 1) / chunk);
+	const int nblocks = (a.nitems + kWavesPerBlock - 1) / kWavesPerBlock;
+	crd_rk4_fused_step_kernel<Real, MODEL><<<nblocks, kLanes * kWavesPerBlock, 0, st>>>(s, a);
+	return hipGetLastError();
+}
+
+}  // namespace
+
+bool fused_step_supported(int, const SlabDesc &d) { return d.nyl >= 2 * kGhost; }
+
 const char *fused_kernel_name(int, int) { return "crd_rk4_fused_step_kernel"; }
-hipError_t launch_fused_step(int, const SlabDesc &, const FusedCall &, int, int, hipStream_t) { return hipErrorNotSupported; }
+
+hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, hipStream_t s)
+{
+	static_assert(kApron == kGhost, "the planes carry exactly the ghost rows the fused step consumes");
+	if (precision == CRD_PRECISION_F64)
+		return d.model == CRD_MODEL_FHN ? launch_fused_t<double, CRD_MODEL_FHN>(d, c, row_begin, row_end, d.js, d.ny, s)
+		                                : launch_fused_t<double, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, d.js, d.ny, s);
+	return d.model == CRD_MODEL_FHN ? launch_fused_t<float, CRD_MODEL_FHN>(d, c, row_begin, row_end, d.js, d.ny, s)
+	                                : launch_fused_t<float, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, d.js, d.ny, s);
+}
 
 }  // namespace crd

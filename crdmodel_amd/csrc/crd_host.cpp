@@ -18,7 +18,7 @@ bool validate_params(const crd_params &p, std::string *why)
 	if (p.surface != CRD_SURFACE_TORUS && p.surface != CRD_SURFACE_FLAT) return fail("surface must be CRD_SURFACE_TORUS or CRD_SURFACE_FLAT");
 	if (p.precision != CRD_PRECISION_F64 && p.precision != CRD_PRECISION_F32) return fail("precision must be CRD_PRECISION_F64 or CRD_PRECISION_F32");
 	if (p.nx < 2 || p.nx > INT32_MAX) return fail("nx (thetaMesh / xMesh) must be in [2, 2^31)");
-	if (p.ny < 0) return fail("ny (phiMesh) must be >= 0");
+	if (p.ny < 0 || p.ny > INT32_MAX) return fail("ny (phiMesh) must be in [0, 2^31)");
 	if (!(p.surface_length > 0.0) || !(p.surface_width > 0.0)) return fail("surfaceLength and surfaceWidth must be positive");
 	if (!std::isfinite(p.diffusion) || !std::isfinite(p.beta) || !std::isfinite(p.beta_min) || !std::isfinite(p.beta_max) ||
 	    !std::isfinite(p.t_boundary))

@@ -27,6 +27,8 @@ struct SlabDesc {
 	int wrap;          // 1: single slab, phi neighbours wrap inside the slab; 0: read ghost rows
 	int has_row0;      // slab owns global row 0      (js == 0)
 	int has_rowN;      // slab owns global row ny-1   (je == ny-1)
+	int js;            // global index of local row 0
+	int ny;            // global row count
 	int model;
 	int just_diffusion;
 };

@@ -9,107 +9,18 @@
 // coefficients are per-column tables in HBM (L2-resident); no MFMA -- there is no contraction in this path.
 #include <hip/hip_runtime.h>
 
-#include "crd_internal.h"
-#include "crd_kernels.h"
+#include "crd_device.h"
 
 namespace crd {
 
 namespace {
 
+using namespace dev;
+
 constexpr int kTX = 64;             // tile width = one wavefront along theta
 constexpr int kBY = 4;              // waves per block
 constexpr int kRPT = 4;             // rows per thread
 constexpr int kTY = kBY * kRPT;     // tile height
-constexpr int kNumXcd = 8;
-
-template <typename Real> struct Pair;
-template <> struct Pair<double> { using type = double2; };
-template <> struct Pair<float> { using type = float2; };
-
-template <typename Real>
-struct Slab {
-	const Real *cA, *cP, *brow;
-	Real cX, ka4;
-	int nx, nyl, wrap, has_row0, has_rowN, just_diffusion;
-};
-
-template <typename Real>
-Slab<Real> typed(const SlabDesc &d)
-{
-	Slab<Real> s;
-	s.cA = static_cast<const Real *>(d.cA);
-	s.cP = static_cast<const Real *>(d.cP);
-	s.brow = static_cast<const Real *>(d.brow) + kGhost;  // index by local row
-	s.cX = (Real)d.cX;
-	s.ka4 = (Real)d.ka4;
-	s.nx = d.nx;
-	s.nyl = d.nyl;
-	s.wrap = d.wrap;
-	s.has_row0 = d.has_row0;
-	s.has_rowN = d.has_rowN;
-	s.just_diffusion = d.just_diffusion;
-	return s;
-}
-
-// Pointer to local row 0 of a plane (ghost rows sit at negative row offsets).
-template <typename Real>
-inline Real *row0(void *plane, int nx)
-{
-	return plane ? static_cast<Real *>(plane) + (size_t)kGhost * (size_t)nx : nullptr;
-}
-
-// The point function: diffusion + kinetics of one grid point.
-//   diffusion  src/FHNmodel_torus.cpp:535-537 with the theta-only factors folded into cA / cX / cP
-//   FHN        src/FHNmodel_torus.cpp:657,660
-//   Goldbeter  src/GoldbeterModel_torus.cpp:694-695,715-716 (pow(x,2), pow(x,4) as multiplies)
-//   absorbing  src/FHNmodel_torus.cpp:643-653 (zero = row is a global phi boundary row and t < TBOUNDARY)
-template <typename Real, int MODEL>
-__device__ __forceinline__ void rhs_point(Real uC, Real uW, Real uE, Real uS, Real uN, Real v, Real cA, Real cX, Real cP, Real b,
-                                          Real ka4, bool zero, bool just_diffusion, Real &du, Real &dv)
-{
-	const Real two = (Real)2;
-	const Real diff = cA * (uE - uW) + cX * ((uE - two * uC) + uW) + cP * ((uN - two * uC) + uS);
-	if (MODEL == CRD_MODEL_FHN) {
-		du = diff + (((Real)3.0 * uC - (uC * uC * uC)) - v);
-		dv = (Real)kFhnEpsilon * (uC + b);
-	} else {
-		const Real z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
-		const Real v2 = (Real)kGbVm2 * z2 / ((Real)(kGbK2 * kGbK2) + z2);
-		const Real v3 = (Real)kGbVm3 * y2 * z4 / (((Real)(kGbKr * kGbKr) + y2) * (ka4 + z4));
-		du = diff + ((((((Real)kGbV0 + (Real)kGbV1 * b) - v2) + v3) + (Real)kGbKf * v) - (Real)kGbK * uC);
-		dv = (v2 - v3) - (Real)kGbKf * v;
-		if (just_diffusion) {  // src/GoldbeterModel_torus.cpp:668: the whole reaction block, absorbing rows included, is skipped
-			du = diff;
-			dv = (Real)0;
-			zero = false;
-		}
-	}
-	if (zero) {
-		du = (Real)0;
-		dv = (Real)0;
-	}
-}
-
-// blockIdx -> tile id.  Workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so tile ids that
-// are consecutive in phi would land on eight different L2s and every halo row would be fetched twice from beyond
-// L2.  This bijection hands each XCD one contiguous run of tiles instead.
-__device__ __forceinline__ int xcd_remap(int bid, int nblocks)
-{
-	const int q = nblocks / kNumXcd, rem = nblocks - q * kNumXcd;
-	const int x = bid % kNumXcd, l = bid / kNumXcd;
-	return x * q + (x < rem ? x : rem) + l;
-}
-
-template <typename Real>
-__device__ __forceinline__ int wrap_row(const Slab<Real> &s, int j)
-{
-	if (s.wrap) {
-		if (j < 0) j += s.nyl;
-		else if (j >= s.nyl) j -= s.nyl;
-	}
-	return j;
-}
-
 template <typename Real>
 struct StageArgs {
 	const Real *in_u, *in_v;    // stage input, pointers to local row 0
