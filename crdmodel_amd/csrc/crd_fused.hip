@@ -16,6 +16,7 @@
 // same reason in phi (rows come from the slab's ghost rows, or wrap for a single slab).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "crd_device.h"
@@ -32,7 +33,8 @@ constexpr int kValid = kLanes - 2 * kApron;  // 56 output columns per wavefront
 constexpr int kWavesPerBlock = 4;
 constexpr int kPrefetch = 4;                 // rows in flight per wavefront; equals the unroll factor so slots stay static
 
-// Value held by lane-1 / lane+1 of this wavefront (edge lanes get their own value back: apron garbage by design).
+// Value held by lane-1 / lane+1 of this wavefront (the edge lane gets 0: it is apron garbage by design).  `old` = 0 with
+// bound_ctrl lets the DPP move write its destination without a tied input, i.e. without a copy in front of it.
 template <typename Real>
 __device__ __forceinline__ Real from_lane_below(Real x);
 template <typename Real>
@@ -42,29 +44,29 @@ template <>
 __device__ __forceinline__ double from_lane_below<double>(double x)
 {
 	int lo = __double2loint(x), hi = __double2hiint(x);
-	lo = __builtin_amdgcn_update_dpp(lo, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-	hi = __builtin_amdgcn_update_dpp(hi, hi, 0x138, 0xf, 0xf, false);
+	lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+	hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
 	return __hiloint2double(hi, lo);
 }
 template <>
 __device__ __forceinline__ double from_lane_above<double>(double x)
 {
 	int lo = __double2loint(x), hi = __double2hiint(x);
-	lo = __builtin_amdgcn_update_dpp(lo, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
-	hi = __builtin_amdgcn_update_dpp(hi, hi, 0x130, 0xf, 0xf, false);
+	lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+	hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
 	return __hiloint2double(hi, lo);
 }
 template <>
 __device__ __forceinline__ float from_lane_below<float>(float x)
 {
 	const int v = __float_as_int(x);
-	return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x138, 0xf, 0xf, false));
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true));
 }
 template <>
 __device__ __forceinline__ float from_lane_above<float>(float x)
 {
 	const int v = __float_as_int(x);
-	return __int_as_float(__builtin_amdgcn_update_dpp(v, v, 0x130, 0xf, 0xf, false));
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true));
 }
 
 // A value known to be identical in every lane, moved to scalar registers.
@@ -83,16 +85,20 @@ struct FusedArgs {
 	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
 	int row_begin, row_end;   // rows of the slab this launch produces
 	int chunk;                // rows per work item
-	int nstrips, nitems;
+	int nstrips, nitems, nblocks, remap;
 };
 
-template <typename Real, int MODEL>
+// ABSORB = false compiles the absorbing-row selects out (no stage of the step has t < tBoundary: every launch after the
+// switch-off time, and every launch of a run with tBoundary = 0).
+template <typename Real, int MODEL, bool ABSORB>
 __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
 	const int lane = threadIdx.x & (kLanes - 1);
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
 	// per-row table reads, the boundary-row tests) in scalar registers.
-	const int item = __builtin_amdgcn_readfirstlane((int)blockIdx.x * kWavesPerBlock + (int)(threadIdx.x >> 6));
+	// Blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of work items, so strips
+	// that overlap in theta (adjacent items) and chunks that overlap in phi (items nstrips apart) meet in the same L2.
+	const int item = __builtin_amdgcn_readfirstlane((a.remap ? xcd_remap((int)blockIdx.x, a.nblocks) : (int)blockIdx.x) * kWavesPerBlock + (int)(threadIdx.x >> 6));
 	if (item >= a.nitems) return;
 	// consecutive items walk theta first: the four wavefronts of a block read adjacent, overlapping strips
 	const int strip = item % a.nstrips, chunk = item / a.nstrips;
@@ -176,7 +182,7 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 		if (!GUARDED || m >= 2) {
 			const int c = p - 1;
 			rhs_point<Real, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
-			                       a.absorb[0] && boundary_row(c), jd, du, dv);
+			                       ABSORB && a.absorb[0] && boundary_row(c), jd, du, dv);
 			U1[S1] = u0[S1] + a.h2 * du;
 			V1[S1 & 1] = v0[S1] + a.h2 * dv;
 			aU[S1] = u0[S1] + a.h6 * du;
@@ -186,7 +192,7 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 		if (!GUARDED || m >= 4) {
 			const int c = p - 2;
 			rhs_point<Real, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[S2 & 1], cA, cX, cP, bq[S2], ka4,
-			                       a.absorb[1] && boundary_row(c), jd, du, dv);
+			                       ABSORB && a.absorb[1] && boundary_row(c), jd, du, dv);
 			U2[S2] = u0[S2] + a.h2 * du;
 			V2[S2 & 1] = v0[S2] + a.h2 * dv;
 			aU[S2] += a.h3 * du;
@@ -196,7 +202,7 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 		if (!GUARDED || m >= 6) {
 			const int c = p - 3;
 			rhs_point<Real, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[S3 & 1], cA, cX, cP, bq[S3], ka4,
-			                       a.absorb[2] && boundary_row(c), jd, du, dv);
+			                       ABSORB && a.absorb[2] && boundary_row(c), jd, du, dv);
 			// y3 row p-3 replaces y3 row p-7 in its slot; rows p-5 and p-4 (slots S1, S4) are still needed by stage 4 below
 			const Real y3u = u0[S3] + a.h1 * du;
 			V3[S3 & 1] = v0[S3] + a.h1 * dv;
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 		if (!GUARDED || m >= 8) {
 			const int c = p - 4;
 			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S1], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
-			                       a.absorb[3] && boundary_row(c), jd, du, dv);
+			                       ABSORB && a.absorb[3] && boundary_row(c), jd, du, dv);
 			if (c < j1 && lane_stores) {  // c >= j0 holds from iteration 8 on
 				const ptrdiff_t o = (ptrdiff_t)c * nx + out_col;
 				a.out_u[o] = aU[S4] + a.h6 * du;
@@ -237,6 +243,35 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 	if (m + 2 < niter) iteration(m + 2, integral_constant<int, 2>{}, std::false_type{});
 }
 
+// Rows per work item.  Every item pays 8 apron rows, which argues for long chunks; but the wavefronts of a launch run in
+// "rounds" of (resident wavefront slots) items, a partly filled last round idles most of the chip, unequal wavefront
+// speeds cost about half a round at the end whatever the count, and short chunks keep the rows two phi-neighbouring items
+// share in L2.  Measured on 8192^2 fp64 (147 strips, 4096 slots; 200-step medians, one process, tools/tune_fused.py):
+// chunk 32 0.434 ms, 24 0.451, 50 0.463, 60 0.477, 75 0.494, 128 0.51, 1024 0.62 -- many short items win.  So: 32 rows,
+// halved while the launch would not fill every slot twice.
+template <typename Real, int MODEL>
+int fused_chunk_rows(int nstrips, int rows)
+{
+	static int slots = 0;  // resident wavefronts of this kernel on the current device
+	if (slots == 0) {
+		int dev = 0, cus = 256, blocks_per_cu = 4;
+		hipDeviceProp_t prop;
+		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
+		    blocks_per_cu < 1)
+			blocks_per_cu = 4;
+		(void)hipGetLastError();
+		slots = cus * blocks_per_cu * kWavesPerBlock;
+	}
+	int chunk = 32;
+	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < 2L * slots) chunk /= 2;
+	if (const char *e = std::getenv("CRD_FUSED_CHUNK")) {  // tuning knob
+		const int v = std::atoi(e);
+		if (v >= 1) chunk = v;
+	}
+	return chunk < rows ? chunk : rows;
+}
+
 template <typename Real, int MODEL>
 hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int js, int ny, hipStream_t st)
 {
@@ -257,14 +292,16 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.row_begin = row_begin;
 	a.row_end = row_end;
 	a.nstrips = (d.nx + kValid - 1) / kValid;
-	// Rows per work item: long enough to amortise the 8 apron rows, short enough to give every SIMD several items.
 	const int rows = row_end - row_begin;
-	int chunk = 128;
-	while (chunk > 16 && (long)a.nstrips * ((rows + chunk - 1) / chunk) < 256L * 4 * 6) chunk /= 2;
-	a.chunk = chunk;
-	a.nitems = a.nstrips * ((rows + chunk - 1) / chunk);
+	a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows);
+	a.nitems = a.nstrips * ((rows + a.chunk - 1) / a.chunk);
 	const int nblocks = (a.nitems + kWavesPerBlock - 1) / kWavesPerBlock;
-	crd_rk4_fused_step_kernel<Real, MODEL><<<nblocks, kLanes * kWavesPerBlock, 0, st>>>(s, a);
+	a.nblocks = nblocks;
+	a.remap = std::getenv("CRD_FUSED_REMAP") ? 1 : 0;  // tuning knob: XCD-contiguous item runs (helps long chunks, hurts 32-row ones)
+	if (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3])
+		crd_rk4_fused_step_kernel<Real, MODEL, true><<<nblocks, kLanes * kWavesPerBlock, 0, st>>>(s, a);
+	else
+		crd_rk4_fused_step_kernel<Real, MODEL, false><<<nblocks, kLanes * kWavesPerBlock, 0, st>>>(s, a);
 	return hipGetLastError();
 }
 

@@ -1,0 +1,41 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of fused-stepper variants in ONE process (guide rule: N variants x M rounds, report median/min).
+Variants are environment knobs the launch code reads on every launch: CRD_FUSED_CHUNK, CRD_FUSED_REMAP."""
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import crdmodel_amd as crd  # noqa: E402
+
+n = int(os.environ.get("TUNE_SIZE", "8192"))
+steps = int(os.environ.get("TUNE_STEPS", "200"))
+rounds = int(os.environ.get("TUNE_ROUNDS", "5"))
+variants = [v for v in os.environ.get("TUNE_VARIANTS", "chunk=0;chunk=75;chunk=60").split(";") if v]
+model = os.environ.get("TUNE_MODEL", "fhn")
+prec = os.environ.get("TUNE_PRECISION", "f64")
+
+p = crd.make_params(model, "torus", n, 80.0, 20.0, 0.12, 1.25 if model == "fhn" else 0.4, ny=n, precision=prec)
+dt = 0.8 * crd.stable_dt(p)
+cfg = crd.run_config(p)
+slab = crd.Slab(p)
+slab.set_stepper(os.environ.get("TUNE_STEPPER", "fused"))
+y0 = crd.initial_conditions(cfg)
+slab.upload(y0)
+slab.step_rk4(0.0, dt, 50)
+res = {v: [] for v in variants}
+for r in range(rounds):
+    for v in variants:
+        for k in ("CRD_FUSED_CHUNK", "CRD_FUSED_REMAP"):
+            os.environ.pop(k, None)
+        for kv in v.split(","):
+            key, val = kv.split("=")
+            if key == "chunk" and val != "0":
+                os.environ["CRD_FUSED_CHUNK"] = val
+            if key == "remap" and val == "1":
+                os.environ["CRD_FUSED_REMAP"] = "1"
+        ms, kms, _ = slab.step_rk4_timed(0.0, dt, steps)
+        res[v].append(ms / steps)
+for v in variants:
+    t = res[v]
+    print("%-28s median %.4f ms  min %.4f  max %.4f  -> %.3e pt-steps/s" % (v, statistics.median(t), min(t), max(t), n * n / (statistics.median(t) * 1e-3)))
