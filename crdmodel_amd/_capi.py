@@ -100,6 +100,7 @@ _SIGNATURES = {
     "crd_group_rhs_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
     "crd_step_rk4_timed": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int64, C.POINTER(C.c_double),
                                      C.POINTER(C.c_double), C.POINTER(C.c_int)]),
+    "crd_dominant_kernel_rows": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "crd_dominant_kernel_name": (C.c_char_p, [_vp]),
     "crd_state_max_abs": (C.c_int, [_vp, C.POINTER(C.c_double)]),
 }

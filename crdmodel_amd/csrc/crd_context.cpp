@@ -238,7 +238,7 @@ int staged_step_self(crd_ctx *c, double t, double dt, hipEvent_t *k_begin, hipEv
 	return CRD_OK;
 }
 
-int fused_step_self(crd_ctx *c, double t, double dt, int src, int dst, hipEvent_t *k_begin, hipEvent_t *k_end)
+FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int dst)
 {
 	FusedCall call{};
 	call.dt = dt;
@@ -246,6 +246,12 @@ int fused_step_self(crd_ctx *c, double t, double dt, int src, int dst, hipEvent_
 	for (int k = 0; k < 4; k++) call.absorb[k] = absorbing(c, t + cs[k] * dt) ? 1 : 0;
 	call.y0 = c->planes(src);
 	call.yout = c->planes(dst);
+	return call;
+}
+
+int fused_step_self(crd_ctx *c, double t, double dt, int src, int dst, hipEvent_t *k_begin, hipEvent_t *k_end)
+{
+	const FusedCall call = make_fused_call(c, t, dt, src, dst);
 	if (k_begin) HIP_TRY(c, hipEventRecord(*k_begin, c->compute));
 	HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, c->compute));
 	if (k_end) HIP_TRY(c, hipEventRecord(*k_end, c->compute));
@@ -319,6 +325,42 @@ int staged_step_multi(crd_ctx *const *cs, int n, double t, double dt, bool timed
 	return CRD_OK;
 }
 
+// Fused stepper on several slabs: ONE exchange per step, four ghost rows of both fields.  Per step (src -> dst):
+//   compute: [wait halo(src)] bands [0, B) and [nyl-B, nyl) -> record edges(dst) -> interior [B, nyl-B)
+//   comm:    wait edges(dst) -> exchange 4 ghost rows of dst.u and dst.v -> record halo(dst)
+// so the exchange for the next step overlaps this step's interior launch (which touches neither band nor ghost rows).
+constexpr int kFusedBand = 32;
+
+int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, bool timed_step)
+{
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		const FusedCall call = make_fused_call(c, t, dt, src, dst);
+		const bool split = c->nyl >= 4 * kFusedBand;
+		HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+		if (split) {
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, kFusedBand, c->compute));
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, c->nyl - kFusedBand, c->nyl, c->compute));
+		} else {
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, c->compute));
+		}
+		HIP_TRY(c, hipEventRecord(c->ev_edges, c->compute));
+	}
+	if (int rc = exchange_stage_input(cs, n, dst, kGhost, true)) return rc;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (c->nyl < 4 * kFusedBand) continue;
+		if (int rc = set_device(c)) return rc;
+		const FusedCall call = make_fused_call(c, t, dt, src, dst);
+		const bool timed = timed_step && !c->ev_k.empty();
+		if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
+		HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kFusedBand, c->nyl - kFusedBand, c->compute));
+		if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
+	}
+	return CRD_OK;
+}
+
 constexpr int kMaxTimedLaunches = 64;
 
 int ensure_timing_events(crd_ctx *c)
@@ -369,14 +411,27 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			std::swap(c->plane[crd_ctx::Y][1], c->plane[crd_ctx::SA][1]);
 		}
 	} else {
-		if (stepper != CRD_STEPPER_STAGED) return fail(lead, CRD_EINVAL, "multi-slab runs use the staged stepper in this build");
+		const bool fused = (stepper == CRD_STEPPER_FUSED);
 		if (nsteps > 0)
-			if (int rc = prime_halo(cs, n, crd_ctx::Y, 1, false)) return rc;
+			if (int rc = prime_halo(cs, n, crd_ctx::Y, fused ? kGhost : 1, fused)) return rc;
+		int cur = crd_ctx::Y;
 		for (int64_t s = 0; s < nsteps; s++) {
 			const bool timed_step = timed_launches && s == nsteps / 2;
-			if (int rc = staged_step_multi(cs, n, t0 + (double)s * dt, dt, timed_step)) return rc;
+			const double t = t0 + (double)s * dt;
+			if (fused) {
+				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
+				if (int rc = fused_step_multi(cs, n, t, dt, cur, dst, timed_step)) return rc;
+				cur = dst;
+			} else if (int rc = staged_step_multi(cs, n, t, dt, timed_step)) {
+				return rc;
+			}
 			if (timed_step) timed = 1;
 		}
+		if (cur != crd_ctx::Y)
+			for (int k = 0; k < n; k++) {
+				std::swap(cs[k]->plane[crd_ctx::Y][0], cs[k]->plane[crd_ctx::SA][0]);
+				std::swap(cs[k]->plane[crd_ctx::Y][1], cs[k]->plane[crd_ctx::SA][1]);
+			}
 		// leave every stream of the run ordered behind the last exchange
 		for (int k = 0; k < n; k++) {
 			if (int rc = set_device(cs[k])) return rc;
@@ -733,6 +788,16 @@ int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double 
 	}
 	if (kernel_ms) *kernel_ms = timed ? sum / timed : 0.0;
 	if (launches_per_step) *launches_per_step = (resolve_stepper(c) == CRD_STEPPER_FUSED) ? 1 : 2;
+	return CRD_OK;
+}
+
+int crd_dominant_kernel_rows(const crd_ctx *c, int64_t *rows)
+{
+	if (!c || !rows) return CRD_EINVAL;
+	const int stepper = resolve_stepper(c);
+	if (c->halo == CRD_HALO_SELF) *rows = c->nyl;
+	else if (stepper == CRD_STEPPER_FUSED) *rows = c->nyl >= 4 * kFusedBand ? c->nyl - 2 * kFusedBand : c->nyl;
+	else *rows = c->nyl - 2;
 	return CRD_OK;
 }
 

@@ -194,7 +194,7 @@ int main(int argc, char *argv[])
 			cleanup();
 			return 1;
 		}
-		crd_set_stepper(ctx[(size_t)k], G > 1 ? CRD_STEPPER_STAGED : cfg.stepper);
+		crd_set_stepper(ctx[(size_t)k], cfg.stepper);
 	}
 	if ((rc = crd_comm_attach_local(ctx.data(), G)) != CRD_OK) {
 		die("crd_comm_attach_local", rc, ctx[0]);

@@ -201,6 +201,11 @@ class Slab:
     def synchronize(self):
         self._check(lib().crd_synchronize(self._h), "crd_synchronize")
 
+    def dominant_kernel_rows(self):
+        v = C.c_int64()
+        self._check(lib().crd_dominant_kernel_rows(self._h, C.byref(v)), "crd_dominant_kernel_rows")
+        return v.value
+
     def dominant_kernel(self):
         return lib().crd_dominant_kernel_name(self._h).decode()
 

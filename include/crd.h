@@ -209,6 +209,10 @@ int crd_group_rhs_device(crd_ctx *const *ctxs, int n, double t, const void *cons
 int crd_step_rk4_timed(crd_ctx *ctx, double t0, double dt, int64_t nsteps, double *ms_total, double *kernel_ms,
                        int *launches_per_step);
 
+/* Rows of the slab one timed launch of the dominant kernel covers (all of them for a single slab; the interior, i.e. all
+ * but the edge rows / bands that are launched separately ahead of the halo exchange, for a multi-slab context). */
+int crd_dominant_kernel_rows(const crd_ctx *ctx, int64_t *rows);
+
 /* Name of the dominant kernel as it appears in a rocprofv3 kernel trace (static string). */
 const char *crd_dominant_kernel_name(const crd_ctx *ctx);
 
