@@ -83,7 +83,9 @@ struct FusedArgs {
 	Real h2, h3, h6, h1;      // dt/2, dt/3, dt/6, dt
 	int absorb[4];            // t_stage < tBoundary for the four stages
 	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
-	int row_begin, row_end;   // rows of the slab this launch produces
+	int row_begin, row_end;   // rows of the slab this launch produces ...
+	int row_begin2, row_end2; // ... plus an optional second range (the two edge bands of a slab go in one launch)
+	int nchunks1;             // chunks of the first range
 	int chunk;                // rows per work item
 	int nstrips, nitems, nblocks, remap;
 };
@@ -110,8 +112,10 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 	const int out_col = strip * kValid + (lane - kApron);
 	const bool lane_stores = lane >= kApron && lane < kLanes - kApron && out_col < nx;
 
-	const int j0 = a.row_begin + chunk * a.chunk;
-	const int j1 = (j0 + a.chunk < a.row_end) ? j0 + a.chunk : a.row_end;
+	const bool second = chunk >= a.nchunks1;
+	const int range_end = second ? a.row_end2 : a.row_end;
+	const int j0 = second ? a.row_begin2 + (chunk - a.nchunks1) * a.chunk : a.row_begin + chunk * a.chunk;
+	const int j1 = (j0 + a.chunk < range_end) ? j0 + a.chunk : range_end;
 	const int jbase = j0 - kApron;
 	const int niter = (j1 - j0) + 2 * kApron;  // >= 9
 	const int jlast = j1 + kApron - 1;         // last row the pipeline consumes
@@ -273,9 +277,13 @@ int fused_chunk_rows(int nstrips, int rows)
 }
 
 template <typename Real, int MODEL>
-hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int js, int ny, hipStream_t st)
+hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, int js, int ny,
+                          hipStream_t st)
 {
 	if (row_end <= row_begin) return hipSuccess;
+	if (row_end2 < row_begin2) row_end2 = row_begin2;
+	// rows may extend into the ghost region (deep-halo steps), but the pipeline reads kStepHalo rows beyond them
+	if (!d.wrap && (row_begin < -(kGhost - kStepHalo) || row_end > d.nyl + (kGhost - kStepHalo))) return hipErrorInvalidValue;
 	const Slab<Real> s = typed<Real>(d);
 	FusedArgs<Real> a;
 	a.in_u = row0<Real>(c.y0.u, d.nx);
@@ -292,9 +300,12 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.row_begin = row_begin;
 	a.row_end = row_end;
 	a.nstrips = (d.nx + kValid - 1) / kValid;
-	const int rows = row_end - row_begin;
-	a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows);
-	a.nitems = a.nstrips * ((rows + a.chunk - 1) / a.chunk);
+	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
+	a.row_begin2 = row_begin2;
+	a.row_end2 = row_end2;
+	a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2);
+	a.nchunks1 = (rows + a.chunk - 1) / a.chunk;
+	a.nitems = a.nstrips * (a.nchunks1 + (rows2 + a.chunk - 1) / a.chunk);
 	const int nblocks = (a.nitems + kWavesPerBlock - 1) / kWavesPerBlock;
 	a.nblocks = nblocks;
 	a.remap = std::getenv("CRD_FUSED_REMAP") ? 1 : 0;  // tuning knob: XCD-contiguous item runs (helps long chunks, hurts 32-row ones)
@@ -307,18 +318,19 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 
 }  // namespace
 
-bool fused_step_supported(int, const SlabDesc &d) { return d.nyl >= 2 * kGhost; }
+bool fused_step_supported(int, const SlabDesc &d) { return d.nyl >= 2 * kStepHalo; }
 
 const char *fused_kernel_name(int, int) { return "crd_rk4_fused_step_kernel"; }
 
-hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, hipStream_t s)
+hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
+                             hipStream_t s)
 {
-	static_assert(kApron == kGhost, "the planes carry exactly the ghost rows the fused step consumes");
+	static_assert(kApron == kStepHalo && kGhost >= kStepHalo, "the planes carry at least the ghost rows one fused step consumes");
 	if (precision == CRD_PRECISION_F64)
-		return d.model == CRD_MODEL_FHN ? launch_fused_t<double, CRD_MODEL_FHN>(d, c, row_begin, row_end, d.js, d.ny, s)
-		                                : launch_fused_t<double, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, d.js, d.ny, s);
-	return d.model == CRD_MODEL_FHN ? launch_fused_t<float, CRD_MODEL_FHN>(d, c, row_begin, row_end, d.js, d.ny, s)
-	                                : launch_fused_t<float, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, d.js, d.ny, s);
+		return d.model == CRD_MODEL_FHN ? launch_fused_t<double, CRD_MODEL_FHN>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s)
+		                                : launch_fused_t<double, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s);
+	return d.model == CRD_MODEL_FHN ? launch_fused_t<float, CRD_MODEL_FHN>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s)
+	                                : launch_fused_t<float, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s);
 }
 
 }  // namespace crd

@@ -16,8 +16,13 @@ constexpr double kFhnEpsilon = 0.36;        // src/FHNmodel_torus.cpp:68
 constexpr double kGbV0 = 1.0, kGbK = 10.0, kGbKf = 1.0, kGbV1 = 7.3, kGbVm2 = 65.0, kGbVm3 = 500.0;
 constexpr double kGbK2 = 1.0, kGbKr = 2.0, kGbKa = 0.9;
 
-// Number of ghost rows kept above and below every slab plane (the fused stepper consumes four per step).
-constexpr int kGhost = 4;
+// Rows one fused RK4 step consumes on each side of the rows it produces (one per stage).
+constexpr int kStepHalo = 4;
+// Fused steps between two halo exchanges of a multi-slab run: the exchange moves kStepHalo * kExchangeEvery ghost rows and
+// each slab recomputes the shrinking ghost region redundantly in between (communication-avoiding deep halo).
+constexpr int kExchangeEvery = 4;
+// Ghost rows kept above and below every slab plane.
+constexpr int kGhost = kStepHalo * kExchangeEvery;
 
 // Host-side coefficient tables of the diffusion operator written as
 //   du = cA[i] (uE - uW) + cX (uE - 2 uC + uW) + cP[i] (uN - 2 uC + uS)

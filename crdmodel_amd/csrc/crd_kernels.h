@@ -53,14 +53,15 @@ hipError_t launch_stage(int precision, const SlabDesc &d, const StageCall &c, in
 const char *stage_kernel_name(int precision, int model);
 
 // Whole RK4 step in one launch (all four stages on chip); reads y0 with kGhost ghost rows, writes yout rows
-// [row_begin, row_end).  absorb[k] = t_stage_k < tBoundary for the four stages.
+// [row_begin, row_end) and, if non-empty, [row_begin2, row_end2).  absorb[k] = t_stage_k < tBoundary for the four stages.
 struct FusedCall {
 	double dt;
 	int absorb[4];
 	Planes y0;
 	Planes yout;
 };
-hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, hipStream_t s);
+hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
+                             hipStream_t s);
 const char *fused_kernel_name(int precision, int model);
 bool fused_step_supported(int precision, const SlabDesc &d);
 

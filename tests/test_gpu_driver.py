@@ -32,7 +32,7 @@ def oracle_outputs(cfg):
     return np.stack(frames)
 
 
-@pytest.mark.parametrize("argv", [["FHNmodel_torus"], ["crd_run", "--model", "fhn", "--surface", "torus", "--gpus", "3", "--devices", "1", "--quiet"]])
+@pytest.mark.parametrize("argv", [["FHNmodel_torus"], ["crd_run", "--model", "fhn", "--surface", "torus", "--gpus", "2", "--devices", "1", "--quiet"]])
 def test_driver_writes_reference_format(gpu_device, tmp_path, argv):
     cfg = crd.load_ini(INI, "fhn", "torus")
     exe = os.path.join(BIN, argv[0])
@@ -44,7 +44,7 @@ def test_driver_writes_reference_format(gpu_device, tmp_path, argv):
     want = oracle_outputs(cfg)
     u, meta = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "u")
     v, _ = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "v")  # includeAllVars = 1 in this ini
-    assert meta["nprocs"] == (3 if "--gpus" in argv else 1)
+    assert meta["nprocs"] == (2 if "--gpus" in argv else 1)
     assert u.shape == want[..., 0].shape == (cfg.output_timestep + 1, 40, 16)
     assert np.array_equal(u[0], want[0, ..., 0]) and np.array_equal(v[0], want[0, ..., 1])  # IC row is exact
     assert rel_err(u, want[..., 0]) <= 1e-9 and rel_err(v, want[..., 1]) <= 1e-9
