@@ -10,6 +10,7 @@
 #include <ctime>
 #include <iostream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "crd.h"
@@ -183,8 +184,13 @@ int main(int argc, char *argv[])
 
 	std::vector<crd_ctx *> ctx((size_t)G, nullptr);
 	std::vector<crd_writer *> wr((size_t)G, nullptr);
-	std::vector<std::vector<double>> host((size_t)G);
+	// Two host copies of every slab: while the writer thread formats output k from one, the GPU integrates towards
+	// output k+1 and downloads into the other (text output of a large grid costs more than the steps between outputs).
+	std::vector<std::vector<double>> host((size_t)G), host_b((size_t)G);
+	std::thread writer;
+	int writer_rc = CRD_OK;
 	auto cleanup = [&]() {
+		if (writer.joinable()) writer.join();
 		for (auto *w : wr) crd_writer_close(w);
 		for (auto *c : ctx) crd_destroy(c);
 	};
@@ -211,6 +217,7 @@ int main(int argc, char *argv[])
 		int64_t js, je;
 		crd_get_slab(ctx[(size_t)k], &js, &je);
 		host[(size_t)k].resize((size_t)(2 * g.nx * (je - js + 1)));
+		host_b[(size_t)k].resize(host[(size_t)k].size());
 		if ((rc = crd_initial_conditions(&cfg, js, je, host[(size_t)k].data())) != CRD_OK) {
 			die("crd_initial_conditions", rc, nullptr);
 			cleanup();
@@ -231,8 +238,9 @@ int main(int argc, char *argv[])
 	int status = 0;
 	for (int iout = 0; iout < Nt; iout++) {
 		const double t = iout * dTout;
+		auto &buf = (iout & 1) ? host_b : host;  // the other set may still be in the writer's hands
 		rc = crd_group_step_rk4(ctx.data(), G, t, dt, steps_per_output);
-		for (int k = 0; k < G && rc == CRD_OK; k++) rc = crd_state_download(ctx[(size_t)k], host[(size_t)k].data(), 1);
+		for (int k = 0; k < G && rc == CRD_OK; k++) rc = crd_state_download(ctx[(size_t)k], buf[(size_t)k].data(), 1);
 		double peak = 0;
 		if (rc == CRD_OK) rc = crd_state_max_abs(ctx[0], &peak);
 		if (rc != CRD_OK || !std::isfinite(peak)) {
@@ -241,13 +249,15 @@ int main(int argc, char *argv[])
 			status = 1;
 			break;
 		}
-		for (int k = 0; k < G; k++)
-			if ((rc = crd_writer_write_row(wr[(size_t)k], host[(size_t)k].data())) != CRD_OK) {
-				die("crd_writer_write_row", rc, nullptr);
-				status = 1;
-				break;
-			}
-		if (status) break;
+		if (writer.joinable()) writer.join();
+		if (writer_rc != CRD_OK) {
+			die("crd_writer_write_row", writer_rc, nullptr);
+			status = 1;
+			break;
+		}
+		writer = std::thread([&wr, &buf, &writer_rc, G]() {
+			for (int k = 0; k < G && writer_rc == CRD_OK; k++) writer_rc = crd_writer_write_row(wr[(size_t)k], buf[(size_t)k].data());
+		});
 
 		// progress line, src/FHNmodel_torus.cpp:457-477
 		time(&end_t);
@@ -261,6 +271,8 @@ int main(int argc, char *argv[])
 			std::fflush(stdout);
 		}
 	}
+	if (writer.joinable()) writer.join();
+	if (writer_rc != CRD_OK && status == 0) status = die("crd_writer_write_row", writer_rc, nullptr);
 	if (!o.quiet) std::cout << "\n   ----------------------\n";
 	cleanup();
 	return status;
