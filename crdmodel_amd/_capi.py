@@ -52,6 +52,20 @@ class HaloOp(C.Structure):
     _fields_ = [("is_send", C.c_int32), ("peer", C.c_int32), ("row_begin", C.c_int64), ("row_count", C.c_int64)]
 
 
+class AdaptiveOptions(C.Structure):
+    """crd_adaptive_options"""
+
+    _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("h0", C.c_double), ("safety", C.c_double), ("bias", C.c_double),
+                ("growth", C.c_double), ("shrink", C.c_double), ("max_steps", C.c_int64)]
+
+
+class AdaptiveStats(C.Structure):
+    """crd_adaptive_stats"""
+
+    _fields_ = [("accepted", C.c_int64), ("rejected", C.c_int64), ("h_last", C.c_double), ("h_next", C.c_double), ("h_min", C.c_double),
+                ("h_max", C.c_double), ("err_last", C.c_double), ("t", C.c_double)]
+
+
 class RunConfig(C.Structure):
     """crd_run_config"""
 
@@ -63,6 +77,8 @@ class RunConfig(C.Structure):
         ("include_all_vars", C.c_int32), ("ic_type", C.c_int32),
         ("dt", C.c_double), ("dt_safety", C.c_double),
         ("n_gpus", C.c_int32), ("stepper", C.c_int32),
+        ("adaptive", C.c_int32), ("reserved", C.c_int32),
+        ("rtol", C.c_double), ("atol", C.c_double),
     ]
 
 
@@ -96,6 +112,8 @@ _SIGNATURES = {
     "crd_set_stepper": (C.c_int, [_vp, C.c_int]),
     "crd_step_rk4": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int64]),
     "crd_synchronize": (C.c_int, [_vp]),
+    "crd_adaptive_defaults": (C.c_int, [C.POINTER(AdaptiveOptions)]),
+    "crd_integrate_adaptive": (C.c_int, [_vp, C.c_double, C.c_double, C.POINTER(AdaptiveOptions), C.POINTER(AdaptiveStats)]),
     "crd_group_step_rk4": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.c_double, C.c_int64]),
     "crd_group_rhs_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
     "crd_step_rk4_timed": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int64, C.POINTER(C.c_double),

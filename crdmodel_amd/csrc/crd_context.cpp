@@ -86,6 +86,8 @@ struct crd_ctx {
 	void *ghost_lo = nullptr, *ghost_hi = nullptr;   // var0 of rows -1 / nyl for the AoS RHS (multi-slab)
 	void *edge_lo = nullptr, *edge_hi = nullptr;     // var0 of rows 0 / nyl-1 packed from an AoS vector
 	double *scalar_dev = nullptr;
+	double *err_partials = nullptr;  // adaptive stepping: per-item error sums (lazy)
+	int err_capacity = 0;
 
 	hipStream_t compute = nullptr, comm = nullptr, band = nullptr;
 	bool bands_on_own_stream = true;  // CRD_BAND_STREAM=0: launch the edge bands on the compute stream, ahead of the interior
@@ -598,7 +600,8 @@ void crd_destroy(crd_ctx *c)
 	for (auto &pl : c->plane)
 		for (void *q : pl)
 			if (q) (void)hipFree(q);
-	for (void *q : {c->cA, c->cP, c->brow, c->stage_in, c->stage_out, c->ghost_lo, c->ghost_hi, c->edge_lo, c->edge_hi, (void *)c->scalar_dev})
+	for (void *q : {c->cA, c->cP, c->brow, c->stage_in, c->stage_out, c->ghost_lo, c->ghost_hi, c->edge_lo, c->edge_hi, (void *)c->scalar_dev,
+	                (void *)c->err_partials})
 		if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
 	for (hipEvent_t e : {c->ev_edges, c->ev_halo, c->ev_interior, c->ev_t0, c->ev_t1})
@@ -800,6 +803,107 @@ int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_
 		for (int k = 0; k < n; k++)
 			if (ctxs[k]->halo != CRD_HALO_LOCAL) return fail(ctxs[0], CRD_ESTATE, "group is not attached");
 	return run_steps(ctxs, n, t0, dt, nsteps, nullptr);
+}
+
+int crd_adaptive_defaults(crd_adaptive_options *o)
+{
+	if (!o) return CRD_EINVAL;
+	o->rtol = 1.e-5;   // src/FHNmodel_torus.cpp:197
+	o->atol = 1.e-10;  // :198
+	o->h0 = 0.0;
+	o->safety = 0.96;
+	o->bias = 1.5;
+	o->growth = 20.0;
+	o->shrink = 0.1;
+	o->max_steps = 200000;  // :372
+	return CRD_OK;
+}
+
+int crd_integrate_adaptive(crd_ctx *c, double t0, double tout, const crd_adaptive_options *opt_in, crd_adaptive_stats *stats)
+{
+	if (!c) return CRD_EINVAL;
+	if (c->halo != CRD_HALO_SELF) return fail(c, CRD_ESTATE, "adaptive integration supports single-slab contexts only in this version");
+	if (!fused_step_supported(c->p.precision, c->desc)) return fail(c, CRD_EINVAL, "slab too small for the fused step kernel");
+	crd_adaptive_options o;
+	crd_adaptive_defaults(&o);
+	if (opt_in) o = *opt_in;
+	if (!(o.rtol >= 0.0) || !(o.atol >= 0.0) || !(o.rtol + o.atol > 0.0) || !(o.safety > 0.0) || !(o.bias > 0.0) || !(o.growth >= 1.0) ||
+	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0)
+		return fail(c, CRD_EINVAL, "bad adaptive options / time interval");
+	if (int rc = set_device(c)) return rc;
+	if (!c->err_partials) {
+		c->err_capacity = fused_max_items(c->desc);
+		HIP_TRY(c, hipMalloc((void **)&c->err_partials, sizeof(double) * (size_t)c->err_capacity));
+	}
+	crd_adaptive_stats st{};
+	st.h_min = 0.0;
+	st.t = t0;
+	double t = t0;
+	double h = o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&c->p);
+	const double n_components = 2.0 * (double)c->nx * (double)c->nyl;
+	int cur = crd_ctx::Y;
+	bool after_reject = false;
+	int rc = CRD_OK;
+	while (t < tout) {
+		if (st.accepted + st.rejected >= o.max_steps) {
+			rc = fail(c, CRD_ESTATE, "adaptive integration: max_steps attempts taken before reaching tout");
+			break;
+		}
+		double hh = h;
+		bool clipped = false;
+		if (t + hh >= tout || tout - (t + hh) < 1e-12 * std::fabs(tout)) {  // land on tout exactly; absorb a sliver of a last step
+			hh = tout - t;
+			clipped = true;
+		}
+		if (!(hh > 1e-14 * std::fmax(std::fabs(t), 1e-300)) && !(t == 0.0 && hh > 0.0)) {
+			rc = fail(c, CRD_ESTATE, "adaptive integration: step size underflow");
+			break;
+		}
+		const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
+		FusedCall call = make_fused_call(c, t, hh, cur, dst);
+		call.embed = 1;
+		call.rtol = o.rtol;
+		call.atol = o.atol;
+		call.err_partials = c->err_partials;
+		call.err_capacity = c->err_capacity;
+		call.err_sum = c->scalar_dev;
+		double sum = 0.0;
+		HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
+		HIP_TRY(c, hipMemcpyAsync(&sum, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
+		HIP_TRY(c, hipStreamSynchronize(c->compute));
+		const double err = o.bias * std::sqrt(sum / n_components);
+		st.err_last = err;
+		double eta;
+		if (!(err == err) || std::isinf(err)) eta = o.shrink;                       // NaN / inf: the step blew up
+		else if (err <= 0.0) eta = o.growth;
+		else eta = std::fmin(o.growth, std::fmax(o.shrink, o.safety * std::pow(err, -0.25)));
+		if (err <= 1.0) {
+			t = clipped ? tout : t + hh;
+			cur = dst;
+			st.accepted++;
+			if (after_reject) eta = std::fmin(eta, 1.0);  // no growth right after a rejection
+			after_reject = false;
+			if (!clipped || st.accepted == 1) {
+				st.h_last = hh;
+				st.h_min = (st.h_min == 0.0) ? hh : std::fmin(st.h_min, hh);
+				st.h_max = std::fmax(st.h_max, hh);
+			}
+			if (!clipped) h = hh * eta;
+			else h = std::fmax(h, hh * eta);  // a step shortened to hit tout says nothing against the step it replaced
+		} else {
+			st.rejected++;
+			after_reject = true;
+			h = hh * std::fmin(eta, 0.9);
+		}
+	}
+	if (cur != crd_ctx::Y) {
+		std::swap(c->plane[crd_ctx::Y][0], c->plane[crd_ctx::SA][0]);
+		std::swap(c->plane[crd_ctx::Y][1], c->plane[crd_ctx::SA][1]);
+	}
+	st.t = t;
+	st.h_next = h;
+	if (stats) *stats = st;
+	return rc;
 }
 
 int crd_synchronize(crd_ctx *c)

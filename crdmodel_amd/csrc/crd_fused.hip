@@ -88,37 +88,48 @@ struct FusedArgs {
 	int nchunks1;             // chunks of the first range
 	int chunk;                // rows per work item
 	int nstrips, nitems, nblocks, remap;
+	double *err_partials;     // EMBED: one weighted square sum per work item
+	Real rtol, atol;          // EMBED: error weights 1 / (rtol |y_n| + atol)
 };
 
 // ABSORB = false compiles the absorbing-row selects out (no stage of the step has t < tBoundary: every launch after the
 // switch-off time, and every launch of a run with tBoundary = 0).
-template <typename Real, int MODEL, bool ABSORB>
+// EMBED = true adds a fifth pipeline stage, k5 = f(t + dt, y_new), the third-order embedded solution
+//   yhat = y + dt (k1/6 + k2/3 + k3/3 + k5/6)            (order conditions checked in DESIGN.md)
+// and with it the local error estimate y_new - yhat = dt (k4 - k5)/6, whose weighted square sum
+//   sum_i (err_i / (rtol |y_n,i| + atol))^2
+// over this work item's outputs is written to err_partials[item] (ARKode's WRMS norm, src/FHNmodel_torus.cpp:365, is
+// sqrt(sum / N)).  The propagated solution is classical RK4 either way.  The pipeline is then five rows / columns deep
+// (apron 5, 54 valid lanes) and uses 8 register slots per array, the loop being unrolled 8 times.
+template <typename Real, int MODEL, bool ABSORB, bool EMBED>
 __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
+	constexpr int APRON = EMBED ? kApron + 1 : kApron;
+	constexpr int VALID = kLanes - 2 * APRON;
+	constexpr int M = EMBED ? 8 : 4;  // register slots per pipeline array = unroll factor
 	const int lane = threadIdx.x & (kLanes - 1);
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
 	// per-row table reads, the boundary-row tests) in scalar registers.
-	// Blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of work items, so strips
-	// that overlap in theta (adjacent items) and chunks that overlap in phi (items nstrips apart) meet in the same L2.
+	// Optional remap: blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of items.
 	const int item = __builtin_amdgcn_readfirstlane((a.remap ? xcd_remap((int)blockIdx.x, a.nblocks) : (int)blockIdx.x) * kWavesPerBlock + (int)(threadIdx.x >> 6));
 	if (item >= a.nitems) return;
 	// consecutive items walk theta first: the four wavefronts of a block read adjacent, overlapping strips
 	const int strip = item % a.nstrips, chunk = item / a.nstrips;
 	const int nx = s.nx;
 
-	int x = strip * kValid - kApron + lane;  // this lane's column, wrapped periodically (nx may be smaller than 64)
+	int x = strip * VALID - APRON + lane;  // this lane's column, wrapped periodically (nx may be smaller than 64)
 	x %= nx;
 	if (x < 0) x += nx;
-	const int out_col = strip * kValid + (lane - kApron);
-	const bool lane_stores = lane >= kApron && lane < kLanes - kApron && out_col < nx;
+	const int out_col = strip * VALID + (lane - APRON);
+	const bool lane_stores = lane >= APRON && lane < kLanes - APRON && out_col < nx;
 
 	const bool second = chunk >= a.nchunks1;
 	const int range_end = second ? a.row_end2 : a.row_end;
 	const int j0 = second ? a.row_begin2 + (chunk - a.nchunks1) * a.chunk : a.row_begin + chunk * a.chunk;
 	const int j1 = (j0 + a.chunk < range_end) ? j0 + a.chunk : range_end;
-	const int jbase = j0 - kApron;
-	const int niter = (j1 - j0) + 2 * kApron;  // >= 9
-	const int jlast = j1 + kApron - 1;         // last row the pipeline consumes
+	const int jbase = j0 - APRON;
+	const int niter = (j1 - j0) + 2 * APRON;
+	const int jlast = j1 + APRON - 1;  // last row the pipeline consumes
 
 	const Real cA = s.cA[x], cP = s.cP[x], cX = s.cX, ka4 = s.ka4;
 	const bool jd = s.just_diffusion != 0;
@@ -139,19 +150,21 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 		return gj == 0 || gj == a.ny - 1;
 	};
 
-	// Pipeline registers.  Row jbase+m of an array lives in slot m & 3 (m & 1 for the two-deep v arrays), so with the
-	// loop unrolled four times every access has a compile-time slot and no value is ever moved between registers.
-	Real u0[4], v0[4], U1[4], U2[4], U3[4], V1[2], V2[2], V3[2], aU[4], aV[4];
+	// Pipeline registers.  Row jbase+m of an array lives in slot m mod M (m & 1 for the two-deep v arrays), so with the
+	// loop unrolled M times every access has a compile-time slot and no value is ever moved between registers.
+	Real u0[M], v0[M], U1[M], U2[M], U3[M], V1[2], V2[2], V3[2], aU[M], aV[M];
+	Real U4[M], V4[2], K4U[2], K4V[2];  // EMBED: y_new window and k4 of the last two rows
+	Real err2 = (Real)0;
 #pragma unroll
-	for (int k = 0; k < 4; k++) u0[k] = v0[k] = U1[k] = U2[k] = U3[k] = aU[k] = aV[k] = (Real)0;
-	V1[0] = V1[1] = V2[0] = V2[1] = V3[0] = V3[1] = (Real)0;
+	for (int k = 0; k < M; k++) u0[k] = v0[k] = U1[k] = U2[k] = U3[k] = aU[k] = aV[k] = U4[k] = (Real)0;
+	V1[0] = V1[1] = V2[0] = V2[1] = V3[0] = V3[1] = V4[0] = V4[1] = K4U[0] = K4U[1] = K4V[0] = K4V[1] = (Real)0;
 
 	// Rows are fetched kPrefetch iterations before they enter the pipeline: with ~16 wavefronts per CU one row in flight
 	// per wavefront is far too little to cover HBM latency (Little's law), four rows (8 loads, 4 KiB per wavefront) is enough.
 	// The per-row reaction parameter b(j) rides along: a plain `s.brow[c]` at the point of use is a VECTOR load whose
 	// full latency the stage then waits for (four exposed L2 round trips per iteration, 60 % of the wave's lifetime when
 	// measured); fetched with the row and moved to scalar registers on arrival it costs nothing.
-	Real pu[kPrefetch], pv[kPrefetch], pb[kPrefetch], bq[4];
+	Real pu[kPrefetch], pv[kPrefetch], pb[kPrefetch], bq[M];
 #pragma unroll
 	for (int k = 0; k < kPrefetch; k++) {
 		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
@@ -159,27 +172,30 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 		pu[k] = a.in_u[rb + x];
 		pv[k] = a.in_v[rb + x];
 		pb[k] = s.brow[jr];
-		bq[k] = (Real)0;
 	}
+#pragma unroll
+	for (int k = 0; k < M; k++) bq[k] = (Real)0;
 
-	// One pipeline iteration at m == K (mod 4).  GUARDED: the first 8 iterations of a chunk, where stage k's inputs exist
-	// only from iteration 2k on.
+	// One pipeline iteration at m == K (mod M).  GUARDED: the first iterations of a chunk, where stage k's inputs exist only
+	// from iteration 2k on.
 	auto iteration = [&](int m, auto kk, auto guarded) {
 		constexpr int K = decltype(kk)::value;
 		constexpr bool GUARDED = decltype(guarded)::value;
-		constexpr int S0 = K & 3, S1 = (K + 3) & 3, S2 = (K + 2) & 3, S3 = (K + 1) & 3;  // slots of rows p, p-1, p-2, p-3
-		constexpr int S4 = K & 3;                                                          // row p-4 shares slot with p
+		// slots of rows p, p-1, ... p-6 (with M = 4, row p-4 shares its slot with row p)
+		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M;
+		constexpr int S5 = (K + 2 * M - 5) % M, S6 = (K + 2 * M - 6) % M;
+		constexpr int P = K % kPrefetch;
 		const int p = jbase + m;
-		const Real b4 = bq[S4];  // b of row p-4 (stage 4), read before row p takes over the slot
-		u0[S0] = pu[K];
-		v0[S0] = pv[K];
-		bq[S0] = uniform(pb[K]);
+		const Real b4 = bq[S4];  // b of row p-4 (stage 4), read before row p takes over the slot when M = 4
+		u0[S0] = pu[P];
+		v0[S0] = pv[P];
+		bq[S0] = uniform(pb[P]);
 		{
 			const int pn = (p + kPrefetch < jlast) ? p + kPrefetch : jlast;  // the tail re-reads a valid row instead of running past the plane
 			const ptrdiff_t rb = row_base(pn);
-			pu[K] = a.in_u[rb + x];
-			pv[K] = a.in_v[rb + x];
-			pb[K] = s.brow[pn];
+			pu[P] = a.in_u[rb + x];
+			pv[P] = a.in_v[rb + x];
+			pb[P] = s.brow[pn];
 		}
 		Real du, dv;
 		// ---- stage 1, centre row p-1: y0 rows p-2, p-1, p -----------------------------------------------------
@@ -207,44 +223,90 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 			const int c = p - 3;
 			rhs_point<Real, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[S3 & 1], cA, cX, cP, bq[S3], ka4,
 			                       ABSORB && a.absorb[2] && boundary_row(c), jd, du, dv);
-			// y3 row p-3 replaces y3 row p-7 in its slot; rows p-5 and p-4 (slots S1, S4) are still needed by stage 4 below
-			const Real y3u = u0[S3] + a.h1 * du;
+			U3[S3] = u0[S3] + a.h1 * du;
 			V3[S3 & 1] = v0[S3] + a.h1 * dv;
 			aU[S3] += a.h3 * du;
 			aV[S3] += a.h3 * dv;
-			U3[S3] = y3u;
 		}
 		// ---- stage 4, centre row p-4: y3 rows p-5, p-4, p-3 -> the new state ----------------------------------
 		if (!GUARDED || m >= 8) {
 			const int c = p - 4;
-			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S1], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
+			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
 			                       ABSORB && a.absorb[3] && boundary_row(c), jd, du, dv);
-			if (c < j1 && lane_stores) {  // c >= j0 holds from iteration 8 on
+			const Real nu = aU[S4] + a.h6 * du, nv = aV[S4] + a.h6 * dv;
+			if ((EMBED ? (c >= j0 && c < j1) : c < j1) && lane_stores) {  // without the fifth stage c >= j0 holds from iteration 8 on
 				const ptrdiff_t o = (ptrdiff_t)c * nx + out_col;
-				a.out_u[o] = aU[S4] + a.h6 * du;
-				a.out_v[o] = aV[S4] + a.h6 * dv;
+				a.out_u[o] = nu;
+				a.out_v[o] = nv;
+			}
+			if (EMBED) {
+				U4[S4] = nu;
+				V4[S4 & 1] = nv;
+				K4U[S4 & 1] = du;
+				K4V[S4 & 1] = dv;
+			}
+		}
+		// ---- stage 5 (EMBED), centre row p-5: y_new rows p-6, p-5, p-4 -> k5 and the error of row p-5 ----------
+		if (EMBED && (!GUARDED || m >= 10)) {
+			const int c = p - 5;
+			rhs_point<Real, MODEL>(U4[S5], from_lane_below(U4[S5]), from_lane_above(U4[S5]), U4[S6], U4[S4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
+			                       ABSORB && a.absorb[3] && boundary_row(c), jd, du, dv);  // k5 is evaluated at t + dt, like k4
+			if (lane_stores) {  // rows j0 .. j1-1 exactly: stage 5 starts at iteration 10 (row j0) and the loop ends at row j1-1
+				const Real au = u0[S5] < (Real)0 ? -u0[S5] : u0[S5], av = v0[S5] < (Real)0 ? -v0[S5] : v0[S5];
+				const Real eu = a.h6 * (K4U[S5 & 1] - du) / (a.rtol * au + a.atol);
+				const Real ev = a.h6 * (K4V[S5 & 1] - dv) / (a.rtol * av + a.atol);
+				err2 += eu * eu + ev * ev;
 			}
 		}
 	};
 	using std::integral_constant;
-	iteration(0, integral_constant<int, 0>{}, std::true_type{});
-	iteration(1, integral_constant<int, 1>{}, std::true_type{});
-	iteration(2, integral_constant<int, 2>{}, std::true_type{});
-	iteration(3, integral_constant<int, 3>{}, std::true_type{});
-	iteration(4, integral_constant<int, 0>{}, std::true_type{});
-	iteration(5, integral_constant<int, 1>{}, std::true_type{});
-	iteration(6, integral_constant<int, 2>{}, std::true_type{});
-	iteration(7, integral_constant<int, 3>{}, std::true_type{});
-	int m = 2 * kApron;
-	for (; m + 3 < niter; m += 4) {
-		iteration(m, integral_constant<int, 0>{}, std::false_type{});
-		iteration(m + 1, integral_constant<int, 1>{}, std::false_type{});
-		iteration(m + 2, integral_constant<int, 2>{}, std::false_type{});
-		iteration(m + 3, integral_constant<int, 3>{}, std::false_type{});
+	// guarded prologue: up to the first multiple of M at or beyond 2 * APRON, so the steady-state loop starts at slot 0
+	constexpr int PRO = ((2 * APRON + M - 1) / M) * M;
+	auto prologue = [&](auto... ks) { ((decltype(ks)::value < niter ? iteration(decltype(ks)::value, integral_constant<int, decltype(ks)::value % M>{}, std::true_type{}) : void()), ...); };
+	if constexpr (PRO == 8)
+		prologue(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
+		         integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{});
+	else
+		prologue(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
+		         integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{}, integral_constant<int, 8>{}, integral_constant<int, 9>{},
+		         integral_constant<int, 10>{}, integral_constant<int, 11>{}, integral_constant<int, 12>{}, integral_constant<int, 13>{},
+		         integral_constant<int, 14>{}, integral_constant<int, 15>{});
+	int m = PRO;
+	auto group = [&](int m0, auto... ks) { (iteration(m0 + decltype(ks)::value, ks, std::false_type{}), ...); };
+	auto tail = [&](int m0, auto... ks) { ((m0 + decltype(ks)::value < niter ? iteration(m0 + decltype(ks)::value, ks, std::false_type{}) : void()), ...); };
+	if constexpr (M == 4) {
+		for (; m + 3 < niter; m += 4) group(m, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{});
+		tail(m, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{});
+	} else {
+		for (; m + 7 < niter; m += 8)
+			group(m, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
+			      integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{});
+		tail(m, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
+		     integral_constant<int, 5>{}, integral_constant<int, 6>{});
 	}
-	if (m < niter) iteration(m, integral_constant<int, 0>{}, std::false_type{});
-	if (m + 1 < niter) iteration(m + 1, integral_constant<int, 1>{}, std::false_type{});
-	if (m + 2 < niter) iteration(m + 2, integral_constant<int, 2>{}, std::false_type{});
+	if constexpr (EMBED) {
+		// wavefront sum in a fixed order (butterfly over lane distances 32 .. 1), one partial per work item: the host-side
+		// reduction adds them in item order, so the norm is reproducible run to run
+		double sum = (double)err2;
+		for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+		if (lane == 0) a.err_partials[item] = sum;
+	}
+}
+
+// Adds the per-item error sums in a fixed order (thread t takes items t, t+256, ...; then a fixed LDS tree), so the error
+// norm, and with it every accept / reject decision of the adaptive stepper, is reproducible from run to run.
+__global__ void __launch_bounds__(256) crd_sum_partials_kernel(const double *__restrict__ partials, int n, double *__restrict__ out)
+{
+	__shared__ double part[256];
+	double sum = 0.0;
+	for (int q = threadIdx.x; q < n; q += 256) sum += partials[q];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	for (int w = 128; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *out = part[0];
 }
 
 // Rows per work item.  Every item pays 8 apron rows, which argues for long chunks; but the wavefronts of a launch run in
@@ -261,7 +323,7 @@ int fused_chunk_rows(int nstrips, int rows)
 		int dev = 0, cus = 256, blocks_per_cu = 4;
 		hipDeviceProp_t prop;
 		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, false>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
 		    blocks_per_cu < 1)
 			blocks_per_cu = 4;
 		(void)hipGetLastError();
@@ -299,7 +361,8 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.ny = ny;
 	a.row_begin = row_begin;
 	a.row_end = row_end;
-	a.nstrips = (d.nx + kValid - 1) / kValid;
+	const int valid = c.embed ? kValid - 2 : kValid;  // the embedded estimator's fifth stage costs one more apron column per side
+	a.nstrips = (d.nx + valid - 1) / valid;
 	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
 	a.row_begin2 = row_begin2;
 	a.row_end2 = row_end2;
@@ -309,16 +372,34 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const int nblocks = (a.nitems + kWavesPerBlock - 1) / kWavesPerBlock;
 	a.nblocks = nblocks;
 	a.remap = std::getenv("CRD_FUSED_REMAP") ? 1 : 0;  // tuning knob: XCD-contiguous item runs (helps long chunks, hurts 32-row ones)
-	if (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3])
-		crd_rk4_fused_step_kernel<Real, MODEL, true><<<nblocks, kLanes * kWavesPerBlock, 0, st>>>(s, a);
-	else
-		crd_rk4_fused_step_kernel<Real, MODEL, false><<<nblocks, kLanes * kWavesPerBlock, 0, st>>>(s, a);
+	a.err_partials = c.err_partials;
+	a.rtol = (Real)c.rtol;
+	a.atol = (Real)c.atol;
+	const bool absorb = c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3];
+	const dim3 block(kLanes * kWavesPerBlock);
+	if (c.embed) {
+		if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
+		if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, true, true><<<nblocks, block, 0, st>>>(s, a);
+		else crd_rk4_fused_step_kernel<Real, MODEL, false, true><<<nblocks, block, 0, st>>>(s, a);
+		crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
+	} else if (absorb) {
+		crd_rk4_fused_step_kernel<Real, MODEL, true, false><<<nblocks, block, 0, st>>>(s, a);
+	} else {
+		crd_rk4_fused_step_kernel<Real, MODEL, false, false><<<nblocks, block, 0, st>>>(s, a);
+	}
 	return hipGetLastError();
 }
 
 }  // namespace
 
 bool fused_step_supported(int, const SlabDesc &d) { return d.nyl >= 2 * kStepHalo; }
+
+int fused_max_items(const SlabDesc &d)
+{
+	// upper bound on the work items of any launch on this slab: the narrowest strips, the shortest chunks the heuristic uses
+	const int strips = (d.nx + (kValid - 2) - 1) / (kValid - 2);
+	return strips * ((d.nyl + 2 * kGhost + 7) / 8 + 2);
+}
 
 const char *fused_kernel_name(int, int) { return "crd_rk4_fused_step_kernel"; }
 

@@ -146,6 +146,9 @@ extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd
 	cfg->dt_safety = 0.8;
 	cfg->n_gpus = 1;
 	cfg->stepper = CRD_STEPPER_AUTO;
+	cfg->adaptive = 0;
+	cfg->rtol = 1.e-5;   // src/FHNmodel_torus.cpp:197-198
+	cfg->atol = 1.e-10;
 
 	bool ok = true;
 	auto D = [&](const char *k, double *dst) { ok = ok && ini.get_double(std::string("Parameters.") + k, dst, &why); };
@@ -206,6 +209,9 @@ extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd
 	if (ok && ini.has("Solver.dtSafety")) ok = ini.get_double("Solver.dtSafety", &cfg->dt_safety, &why);
 	if (ok && ini.has("Solver.gpus")) I("Solver.gpus", &cfg->n_gpus);
 	if (ok && ini.has("Solver.stepper")) I("Solver.stepper", &cfg->stepper);
+	if (ok && ini.has("Solver.adaptive")) I("Solver.adaptive", &cfg->adaptive);
+	if (ok && ini.has("Solver.rtol")) ok = ini.get_double("Solver.rtol", &cfg->rtol, &why);
+	if (ok && ini.has("Solver.atol")) ok = ini.get_double("Solver.atol", &cfg->atol, &why);
 	if (ok && ini.has("Solver.precision")) {
 		int32_t bits = 64;
 		I("Solver.precision", &bits);
@@ -224,8 +230,9 @@ extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd
 		set_err(err, err_len, why);
 		return CRD_EINVAL;
 	}
-	if (cfg->output_timestep < 1 || !(cfg->t_final > 0.0) || cfg->n_gpus < 1 || !(cfg->dt >= 0.0) || !(cfg->dt_safety > 0.0)) {
-		set_err(err, err_len, "outputTimestep, tFinal, gpus, dt or dtSafety out of range");
+	if (cfg->output_timestep < 1 || !(cfg->t_final > 0.0) || cfg->n_gpus < 1 || !(cfg->dt >= 0.0) || !(cfg->dt_safety > 0.0) || !(cfg->rtol >= 0.0) ||
+	    !(cfg->atol >= 0.0) || !(cfg->rtol + cfg->atol > 0.0)) {
+		set_err(err, err_len, "outputTimestep, tFinal, gpus, dt, dtSafety, rtol or atol out of range");
 		return CRD_EINVAL;
 	}
 	set_err(err, err_len, "");

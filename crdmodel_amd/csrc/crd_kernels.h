@@ -59,11 +59,18 @@ struct FusedCall {
 	int absorb[4];
 	Planes y0;
 	Planes yout;
+	// embedded error estimate (adaptive stepping): weighted square sum of the local error over the launch's rows
+	int embed = 0;
+	double rtol = 0.0, atol = 0.0;
+	double *err_partials = nullptr;  // device scratch, err_capacity doubles (>= fused_max_items)
+	int err_capacity = 0;
+	double *err_sum = nullptr;       // device: the sum, written by a follow-up reduction on the same stream
 };
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s);
 const char *fused_kernel_name(int precision, int model);
 bool fused_step_supported(int precision, const SlabDesc &d);
+int fused_max_items(const SlabDesc &d);
 
 // Layout adaptors between the AoS boundary layout (host precision: f64 or device precision) and SoA planes.
 hipError_t launch_aos_to_planes(int precision, int src_is_f64, const void *aos, Planes dst, int nx, int nyl, hipStream_t s);

@@ -27,6 +27,7 @@ struct Options {
 	std::string outdir = ".";
 	std::string ini;
 	bool quiet = false;
+	int adaptive = -1;
 };
 
 [[noreturn]] void usage(const char *argv0, bool alias)
@@ -36,7 +37,7 @@ struct Options {
 	} else {
 		std::cerr << "Usage: " << argv0
 		          << " --model fhn|goldbeter --surface torus|flat [--gpus G] [--devices D] [--dt DT] [--stepper auto|staged|fused]\n"
-		             "       [--precision 64|32] [--outdir DIR] [--quiet] <Config file path>\n";
+		             "       [--precision 64|32] [--adaptive|--fixed] [--outdir DIR] [--quiet] <Config file path>\n";
 	}
 	std::exit(EXIT_FAILURE);
 }
@@ -76,7 +77,8 @@ void banner(const crd_run_config &cfg, const crd_grid &g, int n_slabs, int64_t n
 	std::cout << "   Wavelength = " << cfg.wave_length * 100 << "%\n";
 	std::cout << "   Wavewidth = " << cfg.wave_width * 100 << "%\n";
 	if (fhn && torus) std::cout << "   Wave inside = " << cfg.wave_inside << "\n";
-	std::cout << "   integrator = classical RK4 on GPU, dt = " << dt << " (" << steps_per_output << " steps per output)\n";
+	if (cfg.adaptive) std::cout << "   integrator = adaptive RK4(3) on GPU\n   rtol = " << cfg.rtol << "\n   atol = " << cfg.atol << "\n";
+	else std::cout << "   integrator = classical RK4 on GPU, dt = " << dt << " (" << steps_per_output << " steps per output)\n";
 	if (!fhn && p.just_diffusion == 1) {
 		std::cout << "   Diffusion Only\n\n";
 		return;
@@ -137,6 +139,8 @@ int main(int argc, char *argv[])
 			else if (s == "--dt") o.dt = std::atof(next().c_str());
 			else if (s == "--outdir") o.outdir = next();
 			else if (s == "--quiet") o.quiet = true;
+			else if (s == "--adaptive") o.adaptive = 1;
+			else if (s == "--fixed") o.adaptive = 0;
 			else if (s == "--precision") {
 				const std::string v = next();
 				o.precision = v == "32" ? CRD_PRECISION_F32 : v == "64" ? CRD_PRECISION_F64 : -2;
@@ -161,6 +165,11 @@ int main(int argc, char *argv[])
 	if (o.dt > 0) cfg.dt = o.dt;
 	if (o.stepper >= 0) cfg.stepper = o.stepper;
 	if (o.precision >= 0) cfg.params.precision = o.precision;
+	if (o.adaptive >= 0) cfg.adaptive = o.adaptive;
+	if (cfg.adaptive && cfg.n_gpus > 1) {
+		std::cerr << "\nCRD_ERROR: adaptive stepping runs on one GPU in this version (gpus = " << cfg.n_gpus << ")\n\n";
+		return 1;
+	}
 
 	time_t start_t = 0, end_t = 0;
 	double total_t = 0, eta = 0;
@@ -236,10 +245,26 @@ int main(int argc, char *argv[])
 	}
 
 	int status = 0;
+	double adaptive_h = 0.0;
+	long long adaptive_steps = 0, adaptive_rejected = 0;
 	for (int iout = 0; iout < Nt; iout++) {
 		const double t = iout * dTout;
 		auto &buf = (iout & 1) ? host_b : host;  // the other set may still be in the writer's hands
-		rc = crd_group_step_rk4(ctx.data(), G, t, dt, steps_per_output);
+		if (cfg.adaptive) {
+			// one ARKode(...) call per output interval, src/FHNmodel_torus.cpp:423; the controller's step carries over
+			crd_adaptive_options ao;
+			crd_adaptive_defaults(&ao);
+			ao.rtol = cfg.rtol;
+			ao.atol = cfg.atol;
+			ao.h0 = adaptive_h;
+			crd_adaptive_stats as;
+			rc = crd_integrate_adaptive(ctx[0], t, (iout + 1 == Nt) ? cfg.t_final : (iout + 1) * dTout, &ao, &as);
+			adaptive_h = as.h_next;
+			adaptive_steps += as.accepted;
+			adaptive_rejected += as.rejected;
+		} else {
+			rc = crd_group_step_rk4(ctx.data(), G, t, dt, steps_per_output);
+		}
 		for (int k = 0; k < G && rc == CRD_OK; k++) rc = crd_state_download(ctx[(size_t)k], buf[(size_t)k].data(), 1);
 		double peak = 0;
 		if (rc == CRD_OK) rc = crd_state_max_abs(ctx[0], &peak);
@@ -273,6 +298,7 @@ int main(int argc, char *argv[])
 	}
 	if (writer.joinable()) writer.join();
 	if (writer_rc != CRD_OK && status == 0) status = die("crd_writer_write_row", writer_rc, nullptr);
+	if (!o.quiet && cfg.adaptive) std::cout << "\n   steps = " << adaptive_steps << " (+" << adaptive_rejected << " rejected)";
 	if (!o.quiet) std::cout << "\n   ----------------------\n";
 	cleanup();
 	return status;

@@ -70,13 +70,14 @@ def load_ini(path, model, surface):
 
 
 def run_config(params, *, wave_length=0.1, wave_width=0.5, wave_inside=0, output_timestep=1, t_final=1.0,
-               include_all_vars=0, ic_type=0, dt=0.0, dt_safety=0.8, n_gpus=1, stepper=capi.STEPPER_AUTO):
+               include_all_vars=0, ic_type=0, dt=0.0, dt_safety=0.8, n_gpus=1, stepper=capi.STEPPER_AUTO, adaptive=0, rtol=1e-5, atol=1e-10):
     cfg = RunConfig()
     cfg.params = params
     cfg.wave_length, cfg.wave_width, cfg.wave_inside = wave_length, wave_width, wave_inside
     cfg.output_timestep, cfg.t_final = output_timestep, t_final
     cfg.include_all_vars, cfg.ic_type = include_all_vars, ic_type
     cfg.dt, cfg.dt_safety, cfg.n_gpus, cfg.stepper = dt, dt_safety, n_gpus, stepper
+    cfg.adaptive, cfg.rtol, cfg.atol = adaptive, rtol, atol
     return cfg
 
 
@@ -197,6 +198,20 @@ class Slab:
         ms, kms, lps = C.c_double(), C.c_double(), C.c_int()
         self._check(lib().crd_step_rk4_timed(self._h, t0, dt, nsteps, C.byref(ms), C.byref(kms), C.byref(lps)), "crd_step_rk4_timed")
         return ms.value, kms.value, lps.value
+
+    def integrate_adaptive(self, t0, tout, **options):
+        """Error-controlled RK4(3) from t0 to tout; options override crd_adaptive_defaults (rtol, atol, h0, ...).  Returns stats."""
+        opt, st = capi.AdaptiveOptions(), capi.AdaptiveStats()
+        check(lib().crd_adaptive_defaults(C.byref(opt)), "crd_adaptive_defaults")
+        for k, v in options.items():
+            if not hasattr(opt, k):
+                raise TypeError("unknown adaptive option %r" % k)
+            setattr(opt, k, v)
+        rc = lib().crd_integrate_adaptive(self._h, t0, tout, C.byref(opt), C.byref(st))
+        stats = {f: getattr(st, f) for f, _ in st._fields_}
+        if rc != capi.OK:
+            raise CrdError(rc, "crd_integrate_adaptive", lib().crd_last_error(self._h).decode() + " %r" % stats)
+        return stats
 
     def synchronize(self):
         self._check(lib().crd_synchronize(self._h), "crd_synchronize")

@@ -98,6 +98,9 @@ typedef struct crd_run_config {
 	double dt_safety;         /* [Solver] dtSafety, default 0.8 */
 	int32_t n_gpus;           /* [Solver] gpus, default 1 */
 	int32_t stepper;          /* [Solver] stepper: CRD_STEPPER_* */
+	int32_t adaptive;         /* [Solver] adaptive = 1: error-controlled steps (crd_integrate_adaptive) instead of a fixed dt */
+	int32_t reserved;
+	double rtol, atol;        /* [Solver] rtol / atol, defaults 1e-5 / 1e-10 (src/FHNmodel_torus.cpp:197-198) */
 } crd_run_config;
 
 typedef struct crd_ctx crd_ctx;
@@ -196,6 +199,35 @@ int crd_rhs_device(crd_ctx *ctx, double t, const void *y_aos_dev, void *ydot_aos
 int crd_set_stepper(crd_ctx *ctx, int stepper);
 int crd_step_rk4(crd_ctx *ctx, double t0, double dt, int64_t nsteps);
 int crd_synchronize(crd_ctx *ctx);
+
+/* Error-controlled integration from t0 to exactly tout on the resident state: replaces what the reference gets from
+ * ARKodeSStolerances(rtol, atol) + ARKode(..., tout, ..., ARK_NORMAL) (src/FHNmodel_torus.cpp:365,423).  The propagated
+ * solution is classical RK4 (the same one-launch step kernel as crd_step_rk4); a fifth evaluation k5 = f(t+h, y_new) gives
+ * the embedded third-order solution y + h (k1/6 + k2/3 + k3/3 + k5/6) and the local error estimate h (k4 - k5)/6, measured
+ * in ARKode's WRMS norm with weights 1 / (rtol |y_n| + atol); a step is accepted when bias * norm <= 1 and the next step
+ * is safety * h * (bias * norm)^(-1/4), growth-limited (constants in crd_adaptive_options; defaults are ARKode's).
+ * Not ARKode's step sequence: its method table and controller are not in the reference tree.  The last step
+ * is shortened to land on tout (ARKode overshoots and interpolates).  Single-slab contexts only in this version.
+ * h0 = 0 starts from the diffusion-stability step. */
+typedef struct crd_adaptive_options {
+	double rtol, atol;      /* 1e-5, 1e-10 in the reference (src/FHNmodel_torus.cpp:197-198) */
+	double h0;              /* first step; 0 = automatic */
+	double safety;          /* 0.96 */
+	double bias;            /* 1.5 */
+	double growth;          /* 20: largest h_new / h */
+	double shrink;          /* 0.1: smallest h_new / h */
+	int64_t max_steps;      /* 200000 attempts (ARKodeSetMaxNumSteps, :372) */
+} crd_adaptive_options;
+typedef struct crd_adaptive_stats {
+	int64_t accepted, rejected;
+	double h_last;          /* size of the last accepted step that was not shortened to hit tout */
+	double h_next;          /* controller's suggestion for the next call */
+	double h_min, h_max;    /* over accepted steps */
+	double err_last;        /* bias * WRMS norm of the last attempt */
+	double t;               /* time reached (== tout on success) */
+} crd_adaptive_stats;
+int crd_adaptive_defaults(crd_adaptive_options *opt);
+int crd_integrate_adaptive(crd_ctx *ctx, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats);
 
 /* LOCAL groups (several slabs driven by one host thread): the same two operations on every slab of the run in
  * lockstep; ctxs[k] must be slab k of n.  y[k] / ydot[k] are device pointers on ctxs[k]'s device. */

@@ -175,3 +175,56 @@ def rk4(p, y, t0, dt, nsteps, nthreads=1):
     if lib().crd_oracle_rk4(C.byref(p), _dp(out), t0, dt, nsteps, nthreads) != 0:
         raise RuntimeError("crd_oracle_rk4 failed")
     return out
+
+
+def integrate_adaptive(p, y, t0, tout, h0, rtol=1e-5, atol=1e-10, safety=0.96, bias=1.5, growth=20.0, shrink=0.1, max_steps=200000, nthreads=1):
+    """Error-controlled RK4(3) restated on the CPU for the tests: the step-size logic of libcrd's crd_integrate_adaptive
+    around the oracle's f().  Classical RK4 propagates; k5 = f(t+h, y_new) gives the third-order embedded solution
+    y + h (k1/6 + k2/3 + k3/3 + k5/6), i.e. the error estimate h (k4 - k5)/6; WRMS norm with weights 1/(rtol |y_n| + atol)
+    (the tolerances of /root/reference/src/FHNmodel_torus.cpp:197-198,365).  Returns (y(tout), stats)."""
+    y = np.array(y, dtype=np.float64, order="C", copy=True)
+    t, h = float(t0), float(h0)
+    st = dict(accepted=0, rejected=0, h_last=0.0, h_min=0.0, h_max=0.0, err_last=0.0, steps=[])
+    after_reject = False
+    n = y.size
+    while t < tout:
+        if st["accepted"] + st["rejected"] >= max_steps:
+            raise RuntimeError("max_steps")
+        hh, clipped = h, False
+        if t + hh >= tout or tout - (t + hh) < 1e-12 * abs(tout):
+            hh, clipped = tout - t, True
+        k1 = rhs(p, t, y, nthreads=nthreads)
+        k2 = rhs(p, t + 0.5 * hh, y + (0.5 * hh) * k1, nthreads=nthreads)
+        k3 = rhs(p, t + 0.5 * hh, y + (0.5 * hh) * k2, nthreads=nthreads)
+        k4 = rhs(p, t + hh, y + hh * k3, nthreads=nthreads)
+        ynew = y + (hh / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+        k5 = rhs(p, t + hh, ynew, nthreads=nthreads)
+        e = (hh / 6.0) * (k4 - k5) / (rtol * np.abs(y) + atol)
+        err = bias * float(np.sqrt(np.sum(e * e) / n))
+        st["err_last"] = err
+        if not np.isfinite(err):
+            eta = shrink
+        elif err <= 0.0:
+            eta = growth
+        else:
+            eta = min(growth, max(shrink, safety * err ** -0.25))
+        if err <= 1.0:
+            t = tout if clipped else t + hh
+            y = ynew
+            st["accepted"] += 1
+            st["steps"].append(hh)
+            if after_reject:
+                eta = min(eta, 1.0)
+            after_reject = False
+            if not clipped or st["accepted"] == 1:
+                st["h_last"] = hh
+                st["h_min"] = hh if st["h_min"] == 0.0 else min(st["h_min"], hh)
+                st["h_max"] = max(st["h_max"], hh)
+            h = hh * eta if not clipped else max(h, hh * eta)
+        else:
+            st["rejected"] += 1
+            after_reject = True
+            h = hh * min(eta, 0.9)
+    st["h_next"] = h
+    st["t"] = t
+    return y, st

@@ -49,3 +49,29 @@ def test_driver_writes_reference_format(gpu_device, tmp_path, argv):
     assert np.array_equal(u[0], want[0, ..., 0]) and np.array_equal(v[0], want[0, ..., 1])  # IC row is exact
     assert rel_err(u, want[..., 0]) <= 1e-9 and rel_err(v, want[..., 1]) <= 1e-9
     assert np.abs(u[-1] - u[0]).max() > 0.1  # the wave actually moved
+
+
+def test_driver_adaptive_mode(gpu_device, tmp_path):
+    """`--adaptive`: one error-controlled integration per output interval (as the reference calls ARKode once per output),
+    the controller's step carried from interval to interval; checked against the CPU restatement of the same controller."""
+    cfg = crd.load_ini(INI, "fhn", "torus")
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--adaptive", INI], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "integrator = adaptive RK4(3) on GPU" in r.stdout and "rtol = 1e-05" in r.stdout and "steps = " in r.stdout
+    p = cfg.params
+    g = crd.grid_of(p)
+    op = co.make_problem(co.FHN, co.TORUS, g.nx, p.surface_length, p.surface_width, p.diffusion, p.beta, ny=p.ny, t_boundary=p.t_boundary)
+    y = co.initial_conditions(op, cfg.wave_length, cfg.wave_width, cfg.wave_inside, 0)
+    frames, h = [y], 0.8 * crd.stable_dt(p)
+    d_tout = cfg.t_final / cfg.output_timestep
+    for k in range(cfg.output_timestep):
+        y, st = co.integrate_adaptive(op, y, k * d_tout, cfg.t_final if k + 1 == cfg.output_timestep else (k + 1) * d_tout, h)
+        h = st["h_next"]
+        frames.append(y)
+    want = np.stack(frames)
+    u, _ = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "u")
+    assert rel_err(u, want[..., 0]) <= 1e-9
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--adaptive", "--gpus", "2", INI], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "one GPU" in r.stderr
