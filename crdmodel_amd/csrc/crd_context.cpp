@@ -778,6 +778,33 @@ int crd_group_rhs_device(crd_ctx *const *ctxs, int n, double t, const void *cons
 	return CRD_OK;
 }
 
+int crd_group_rhs_host(crd_ctx *const *ctxs, int n, double t, const void *const *y, void *const *ydot)
+{
+	if (int rc = check_group(ctxs, n)) return rc;
+	if (!y || !ydot) return CRD_EINVAL;
+	std::vector<const void *> din((size_t)n);
+	std::vector<void *> dout((size_t)n);
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = ctxs[k];
+		if (!y[k] || !ydot[k]) return CRD_EINVAL;
+		if (int rc = set_device(c)) return rc;
+		const size_t bytes = 2 * (size_t)c->nx * (size_t)c->nyl * c->real_size;
+		if (int rc = ensure_staging(c, 2 * (size_t)c->nx * (size_t)c->nyl * 8)) return rc;
+		HIP_TRY(c, hipMemcpyAsync(c->stage_in, y[k], bytes, hipMemcpyHostToDevice, c->compute));
+		din[(size_t)k] = c->stage_in;
+		dout[(size_t)k] = c->stage_out;
+	}
+	if (int rc = crd_group_rhs_device(ctxs, n, t, din.data(), dout.data())) return rc;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = ctxs[k];
+		if (int rc = set_device(c)) return rc;
+		const size_t bytes = 2 * (size_t)c->nx * (size_t)c->nyl * c->real_size;
+		HIP_TRY(c, hipMemcpyAsync(ydot[k], c->stage_out, bytes, hipMemcpyDeviceToHost, c->compute));
+		HIP_TRY(c, hipStreamSynchronize(c->compute));
+	}
+	return CRD_OK;
+}
+
 int crd_set_stepper(crd_ctx *c, int stepper)
 {
 	if (!c) return CRD_EINVAL;

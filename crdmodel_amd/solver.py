@@ -258,6 +258,16 @@ class LocalGroup:
     def download(self):
         return np.concatenate([s.download() for s in self.slabs], axis=0)
 
+    def f(self, t, y):
+        """ydot = f(t, y) on the whole grid, evaluated slab by slab with halos exchanged between the slabs' vectors."""
+        n = len(self.slabs)
+        parts = [np.ascontiguousarray(y[s.js:s.je + 1], dtype=s.dtype) for s in self.slabs]
+        outs = [np.empty_like(q) for q in parts]
+        ins = (C.c_void_p * n)(*[q.ctypes.data for q in parts])
+        out = (C.c_void_p * n)(*[q.ctypes.data for q in outs])
+        check(lib().crd_group_rhs_host(self._arr, n, t, ins, out), "crd_group_rhs_host", self.slabs[0].handle)
+        return np.concatenate(outs, axis=0)
+
     def step_rk4(self, t0, dt, nsteps):
         check(lib().crd_group_step_rk4(self._arr, len(self.slabs), t0, dt, nsteps), "crd_group_step_rk4", self.slabs[0].handle)
         for s in self.slabs:

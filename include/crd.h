@@ -233,6 +233,7 @@ int crd_integrate_adaptive(crd_ctx *ctx, double t0, double tout, const crd_adapt
  * lockstep; ctxs[k] must be slab k of n.  y[k] / ydot[k] are device pointers on ctxs[k]'s device. */
 int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps);
 int crd_group_rhs_device(crd_ctx *const *ctxs, int n, double t, const void *const *y_aos_dev, void *const *ydot_aos_dev);
+int crd_group_rhs_host(crd_ctx *const *ctxs, int n, double t, const void *const *y_aos, void *const *ydot_aos); /* host vectors, device precision */
 
 /* Same as crd_step_rk4 but bracketed by HIP events on the context's compute stream; blocks until done.
  * ms_total: device time of the whole batch; kernel_ms: average duration of one launch of the dominant kernel
