@@ -172,3 +172,17 @@ def test_ny_truncation_table():
     for e in geo["ny"]:
         g = cn.geometry(e["surface"], e["L"], e["W"], e["nx"])
         assert (g["ny"], g["dx"], g["dy"]) == (e["ny"], e["dx"], e["dy"])
+
+
+def test_adaptive_restatement_is_sane():
+    """The CPU restatement of the error-controlled stepper (used to check libcrd's crd_integrate_adaptive): lands on tout,
+    rejects when started far above the stable step, and converges to a fine fixed-step RK4 solution at the tolerance's scale."""
+    meta, arr = load_golden("rk4_fhn_torus_outside")
+    p = oracle_problem(meta)
+    tout = 1.0
+    y, st = co.integrate_adaptive(p, arr["y0"], 0.0, tout, h0=2.0)
+    assert st["t"] == tout and st["rejected"] >= 1 and st["accepted"] == len(st["steps"]) and abs(sum(st["steps"]) - tout) < 1e-12
+    fine = co.rk4(p, arr["y0"], 0.0, tout / 2000, 2000)
+    assert rel_err(y, fine) <= 1e-3
+    y2, st2 = co.integrate_adaptive(p, arr["y0"], 0.0, tout, h0=2.0, rtol=1e-8, atol=1e-12)
+    assert st2["accepted"] > st["accepted"] and rel_err(y2, fine) < 0.05 * rel_err(y, fine) + 1e-9
