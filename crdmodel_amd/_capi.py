@@ -114,6 +114,8 @@ _SIGNATURES = {
     "crd_synchronize": (C.c_int, [_vp]),
     "crd_adaptive_defaults": (C.c_int, [C.POINTER(AdaptiveOptions)]),
     "crd_integrate_adaptive": (C.c_int, [_vp, C.c_double, C.c_double, C.POINTER(AdaptiveOptions), C.POINTER(AdaptiveStats)]),
+    "crd_group_integrate_adaptive": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.c_double, C.POINTER(AdaptiveOptions),
+                                             C.POINTER(AdaptiveStats)]),
     "crd_group_step_rk4": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.c_double, C.c_int64]),
     "crd_group_rhs_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
     "crd_group_rhs_host": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),

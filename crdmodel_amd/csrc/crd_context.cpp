@@ -30,6 +30,7 @@ struct RcclApi {
 	decltype(&ncclGroupEnd) GroupEnd = nullptr;
 	decltype(&ncclSend) Send = nullptr;
 	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 	std::string error;
 
@@ -57,6 +58,7 @@ struct RcclApi {
 		GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
 		Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
 		Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+		AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
 		GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
 		if (!error.empty()) {
 			handle = nullptr;
@@ -846,34 +848,37 @@ int crd_adaptive_defaults(crd_adaptive_options *o)
 	return CRD_OK;
 }
 
-int crd_integrate_adaptive(crd_ctx *c, double t0, double tout, const crd_adaptive_options *opt_in, crd_adaptive_stats *stats)
+// Error-controlled integration of all slabs of a run (n = 1: a single-slab or RCCL context; n > 1: a LOCAL group).
+static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double tout, const crd_adaptive_options *opt_in, crd_adaptive_stats *stats)
 {
-	if (!c) return CRD_EINVAL;
-	if (c->halo != CRD_HALO_SELF) return fail(c, CRD_ESTATE, "adaptive integration supports single-slab contexts only in this version");
-	if (!fused_step_supported(c->p.precision, c->desc)) return fail(c, CRD_EINVAL, "slab too small for the fused step kernel");
+	crd_ctx *lead = cs[0];
 	crd_adaptive_options o;
 	crd_adaptive_defaults(&o);
 	if (opt_in) o = *opt_in;
 	if (!(o.rtol >= 0.0) || !(o.atol >= 0.0) || !(o.rtol + o.atol > 0.0) || !(o.safety > 0.0) || !(o.bias > 0.0) || !(o.growth >= 1.0) ||
 	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0)
-		return fail(c, CRD_EINVAL, "bad adaptive options / time interval");
-	if (int rc = set_device(c)) return rc;
-	if (!c->err_partials) {
-		c->err_capacity = fused_max_items(c->desc);
-		HIP_TRY(c, hipMalloc((void **)&c->err_partials, sizeof(double) * (size_t)c->err_capacity));
+		return fail(lead, CRD_EINVAL, "bad adaptive options / time interval");
+	const bool multi = lead->halo != CRD_HALO_SELF;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (!fused_step_supported(c->p.precision, c->desc)) return fail(lead, CRD_EINVAL, "slab too small for the fused step kernel");
+		if (int rc = set_device(c)) return rc;
+		if (!c->err_partials) {
+			c->err_capacity = fused_max_items(c->desc);
+			HIP_TRY(c, hipMalloc((void **)&c->err_partials, sizeof(double) * (size_t)c->err_capacity));
+		}
 	}
 	crd_adaptive_stats st{};
-	st.h_min = 0.0;
-	st.t = t0;
 	double t = t0;
-	double h = o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&c->p);
-	const double n_components = 2.0 * (double)c->nx * (double)c->nyl;
+	double h = o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&lead->p);
+	const double n_components = 2.0 * (double)lead->g.nx * (double)lead->g.ny;  // WRMS norm over the whole grid
+	constexpr int kEmbedHalo = kStepHalo + 1;                                     // the fifth stage reads one more row
 	int cur = crd_ctx::Y;
 	bool after_reject = false;
 	int rc = CRD_OK;
 	while (t < tout) {
 		if (st.accepted + st.rejected >= o.max_steps) {
-			rc = fail(c, CRD_ESTATE, "adaptive integration: max_steps attempts taken before reaching tout");
+			rc = fail(lead, CRD_ESTATE, "adaptive integration: max_steps attempts taken before reaching tout");
 			break;
 		}
 		double hh = h;
@@ -883,25 +888,41 @@ int crd_integrate_adaptive(crd_ctx *c, double t0, double tout, const crd_adaptiv
 			clipped = true;
 		}
 		if (!(hh > 1e-14 * std::fmax(std::fabs(t), 1e-300)) && !(t == 0.0 && hh > 0.0)) {
-			rc = fail(c, CRD_ESTATE, "adaptive integration: step size underflow");
+			rc = fail(lead, CRD_ESTATE, "adaptive integration: step size underflow");
 			break;
 		}
 		const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
-		FusedCall call = make_fused_call(c, t, hh, cur, dst);
-		call.embed = 1;
-		call.rtol = o.rtol;
-		call.atol = o.atol;
-		call.err_partials = c->err_partials;
-		call.err_capacity = c->err_capacity;
-		call.err_sum = c->scalar_dev;
+		if (multi)  // every attempt starts from freshly exchanged ghost rows of the current state (no overlap: the host waits for the norm anyway)
+			if ((rc = prime_halo(cs, n, cur, kEmbedHalo, true))) break;
 		double sum = 0.0;
-		HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
-		HIP_TRY(c, hipMemcpyAsync(&sum, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
-		HIP_TRY(c, hipStreamSynchronize(c->compute));
+		for (int k = 0; k < n && rc == CRD_OK; k++) {
+			crd_ctx *c = cs[k];
+			if ((rc = set_device(c))) break;
+			FusedCall call = make_fused_call(c, t, hh, cur, dst);
+			call.embed = 1;
+			call.rtol = o.rtol;
+			call.atol = o.atol;
+			call.err_partials = c->err_partials;
+			call.err_capacity = c->err_capacity;
+			call.err_sum = c->scalar_dev;
+			if (multi) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
+			if (c->halo == CRD_HALO_RCCL)  // every rank gets the same bits, hence takes the same decision
+				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev, c->scalar_dev, 1, ncclDouble, ncclSum, c->nccl, c->compute));
+		}
+		for (int k = 0; k < n && rc == CRD_OK; k++) {  // LOCAL groups: add the slabs' sums in slab order
+			crd_ctx *c = cs[k];
+			if ((rc = set_device(c))) break;
+			double part = 0.0;
+			HIP_TRY(c, hipMemcpyAsync(&part, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
+			HIP_TRY(c, hipStreamSynchronize(c->compute));
+			sum += part;
+		}
+		if (rc != CRD_OK) break;
 		const double err = o.bias * std::sqrt(sum / n_components);
 		st.err_last = err;
 		double eta;
-		if (!(err == err) || std::isinf(err)) eta = o.shrink;                       // NaN / inf: the step blew up
+		if (!(err == err) || std::isinf(err)) eta = o.shrink;  // NaN / inf: the step blew up
 		else if (err <= 0.0) eta = o.growth;
 		else eta = std::fmin(o.growth, std::fmax(o.shrink, o.safety * std::pow(err, -0.25)));
 		if (err <= 1.0) {
@@ -923,14 +944,33 @@ int crd_integrate_adaptive(crd_ctx *c, double t0, double tout, const crd_adaptiv
 			h = hh * std::fmin(eta, 0.9);
 		}
 	}
-	if (cur != crd_ctx::Y) {
-		std::swap(c->plane[crd_ctx::Y][0], c->plane[crd_ctx::SA][0]);
-		std::swap(c->plane[crd_ctx::Y][1], c->plane[crd_ctx::SA][1]);
-	}
+	if (cur != crd_ctx::Y)
+		for (int k = 0; k < n; k++) {
+			std::swap(cs[k]->plane[crd_ctx::Y][0], cs[k]->plane[crd_ctx::SA][0]);
+			std::swap(cs[k]->plane[crd_ctx::Y][1], cs[k]->plane[crd_ctx::SA][1]);
+		}
 	st.t = t;
 	st.h_next = h;
 	if (stats) *stats = st;
 	return rc;
+}
+
+int crd_integrate_adaptive(crd_ctx *c, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats)
+{
+	if (!c) return CRD_EINVAL;
+	if (c->halo < 0) return fail(c, CRD_ESTATE, "multi-slab context is not wired (crd_comm_attach_local / crd_comm_init_rccl)");
+	if (c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "LOCAL groups integrate through crd_group_integrate_adaptive");
+	crd_ctx *one[1] = {c};
+	return integrate_adaptive_impl(one, 1, t0, tout, opt, stats);
+}
+
+int crd_group_integrate_adaptive(crd_ctx *const *ctxs, int n, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats)
+{
+	if (int rc = check_group(ctxs, n)) return rc;
+	if (n > 1)
+		for (int k = 0; k < n; k++)
+			if (ctxs[k]->halo != CRD_HALO_LOCAL) return fail(ctxs[0], CRD_ESTATE, "group is not attached");
+	return integrate_adaptive_impl(ctxs, n, t0, tout, opt, stats);
 }
 
 int crd_synchronize(crd_ctx *c)

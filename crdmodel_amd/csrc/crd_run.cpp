@@ -166,11 +166,6 @@ int main(int argc, char *argv[])
 	if (o.stepper >= 0) cfg.stepper = o.stepper;
 	if (o.precision >= 0) cfg.params.precision = o.precision;
 	if (o.adaptive >= 0) cfg.adaptive = o.adaptive;
-	if (cfg.adaptive && cfg.n_gpus > 1) {
-		std::cerr << "\nCRD_ERROR: adaptive stepping runs on one GPU in this version (gpus = " << cfg.n_gpus << ")\n\n";
-		return 1;
-	}
-
 	time_t start_t = 0, end_t = 0;
 	double total_t = 0, eta = 0;
 	time(&start_t);
@@ -258,7 +253,7 @@ int main(int argc, char *argv[])
 			ao.atol = cfg.atol;
 			ao.h0 = adaptive_h;
 			crd_adaptive_stats as;
-			rc = crd_integrate_adaptive(ctx[0], t, (iout + 1 == Nt) ? cfg.t_final : (iout + 1) * dTout, &ao, &as);
+			rc = crd_group_integrate_adaptive(ctx.data(), G, t, (iout + 1 == Nt) ? cfg.t_final : (iout + 1) * dTout, &ao, &as);
 			adaptive_h = as.h_next;
 			adaptive_steps += as.accepted;
 			adaptive_rejected += as.rejected;

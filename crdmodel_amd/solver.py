@@ -114,6 +114,23 @@ class Writer:
         self.close()
 
 
+def _adaptive_options(options):
+    opt = capi.AdaptiveOptions()
+    check(lib().crd_adaptive_defaults(C.byref(opt)), "crd_adaptive_defaults")
+    for k, v in options.items():
+        if not hasattr(opt, k):
+            raise TypeError("unknown adaptive option %r" % k)
+        setattr(opt, k, v)
+    return opt
+
+
+def _adaptive_result(rc, st, where, handle):
+    stats = {f: getattr(st, f) for f, _ in st._fields_}
+    if rc != capi.OK:
+        raise CrdError(rc, where, lib().crd_last_error(handle).decode() + " %r" % stats)
+    return stats
+
+
 class Slab:
     """One phi-slab of the grid resident on one GPU (crd_ctx)."""
 
@@ -201,17 +218,9 @@ class Slab:
 
     def integrate_adaptive(self, t0, tout, **options):
         """Error-controlled RK4(3) from t0 to tout; options override crd_adaptive_defaults (rtol, atol, h0, ...).  Returns stats."""
-        opt, st = capi.AdaptiveOptions(), capi.AdaptiveStats()
-        check(lib().crd_adaptive_defaults(C.byref(opt)), "crd_adaptive_defaults")
-        for k, v in options.items():
-            if not hasattr(opt, k):
-                raise TypeError("unknown adaptive option %r" % k)
-            setattr(opt, k, v)
+        opt, st = _adaptive_options(options), capi.AdaptiveStats()
         rc = lib().crd_integrate_adaptive(self._h, t0, tout, C.byref(opt), C.byref(st))
-        stats = {f: getattr(st, f) for f, _ in st._fields_}
-        if rc != capi.OK:
-            raise CrdError(rc, "crd_integrate_adaptive", lib().crd_last_error(self._h).decode() + " %r" % stats)
-        return stats
+        return _adaptive_result(rc, st, "crd_integrate_adaptive", self._h)
 
     def synchronize(self):
         self._check(lib().crd_synchronize(self._h), "crd_synchronize")
@@ -276,6 +285,14 @@ class LocalGroup:
     def set_stepper(self, stepper):
         for s in self.slabs:
             s.set_stepper(stepper)
+
+    def integrate_adaptive(self, t0, tout, **options):
+        opt, st = _adaptive_options(options), capi.AdaptiveStats()
+        rc = lib().crd_group_integrate_adaptive(self._arr, len(self.slabs), t0, tout, C.byref(opt), C.byref(st))
+        stats = _adaptive_result(rc, st, "crd_group_integrate_adaptive", self.slabs[0].handle)
+        for s in self.slabs:
+            s.synchronize()
+        return stats
 
     def close(self):
         for s in self.slabs:

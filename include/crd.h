@@ -207,8 +207,9 @@ int crd_synchronize(crd_ctx *ctx);
  * in ARKode's WRMS norm with weights 1 / (rtol |y_n| + atol); a step is accepted when bias * norm <= 1 and the next step
  * is safety * h * (bias * norm)^(-1/4), growth-limited (constants in crd_adaptive_options; defaults are ARKode's).
  * Not ARKode's step sequence: its method table and controller are not in the reference tree.  The last step
- * is shortened to land on tout (ARKode overshoots and interpolates).  Single-slab contexts only in this version.
- * h0 = 0 starts from the diffusion-stability step. */
+ * is shortened to land on tout (ARKode overshoots and interpolates).  Multi-slab runs exchange five ghost rows before
+ * every attempt and reduce the norm over the ring (ncclAllReduce; LOCAL groups add the slabs' sums on the host in slab
+ * order), so every rank takes the same decisions.  h0 = 0 starts from the diffusion-stability step. */
 typedef struct crd_adaptive_options {
 	double rtol, atol;      /* 1e-5, 1e-10 in the reference (src/FHNmodel_torus.cpp:197-198) */
 	double h0;              /* first step; 0 = automatic */
@@ -228,6 +229,8 @@ typedef struct crd_adaptive_stats {
 } crd_adaptive_stats;
 int crd_adaptive_defaults(crd_adaptive_options *opt);
 int crd_integrate_adaptive(crd_ctx *ctx, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats);
+int crd_group_integrate_adaptive(crd_ctx *const *ctxs, int n, double t0, double tout, const crd_adaptive_options *opt,
+                                 crd_adaptive_stats *stats); /* LOCAL groups */
 
 /* LOCAL groups (several slabs driven by one host thread): the same two operations on every slab of the run in
  * lockstep; ctxs[k] must be slab k of n.  y[k] / ydot[k] are device pointers on ctxs[k]'s device. */

@@ -72,6 +72,11 @@ def test_driver_adaptive_mode(gpu_device, tmp_path):
     want = np.stack(frames)
     u, _ = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "u")
     assert rel_err(u, want[..., 0]) <= 1e-9
-    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--adaptive", "--gpus", "2", INI], cwd=tmp_path,
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 1 and "one GPU" in r.stderr
+    # two slabs: same controller, halos per attempt, norm summed over the slabs -> the same files up to round-off
+    out2 = tmp_path / "two"
+    out2.mkdir()
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--adaptive", "--gpus", "2", "--devices", "1", "--quiet", INI],
+                       cwd=out2, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    u2, meta2 = load_like_the_plot_script(out2, "FHNmodel_torus", "u")
+    assert meta2["nprocs"] == 2 and rel_err(u2, want[..., 0]) <= 1e-9
