@@ -5,7 +5,7 @@
 // Structure (no LDS, no barriers, no MFMA): every WAVEFRONT is an independent work item.  It owns a strip of 64
 // consecutive theta columns -- one column per lane, 56 valid outputs in the middle and a 4-column apron on each side
 // that is recomputed redundantly -- and marches along phi through a chunk of rows as a 4-deep software pipeline:
-//   iteration m:  load row p        (state y0, prefetched one iteration ahead)
+//   iteration m:  take row p        (state y0, fetched four iterations earlier)
 //                 stage 1 on row p-1 (needs y0 rows p-2..p)          -> y1 row p-1, acc row p-1
 //                 stage 2 on row p-2 (needs y1 rows p-3..p-1)        -> y2 row p-2
 //                 stage 3 on row p-3 (needs y2 rows p-4..p-2)        -> y3 row p-3
