@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <new>
 
 #include "crd_internal.h"
@@ -70,6 +71,23 @@ struct RcclApi {
 RcclApi g_rccl;
 }
 
+// The three streams of a context: interior sweeps, edge bands (high priority), halo exchange.  Contexts of a LOCAL group
+// that share a device share one set (crd_comm_attach_local), so a device never carries more than three of this library's
+// streams however many slabs it hosts.
+struct StreamSet {
+	int device = 0;
+	hipStream_t compute = nullptr, comm = nullptr, band = nullptr;
+	~StreamSet()
+	{
+		(void)hipSetDevice(device);
+		for (hipStream_t s : {compute, comm, band})
+			if (s) {
+				(void)hipStreamSynchronize(s);
+				(void)hipStreamDestroy(s);
+			}
+	}
+};
+
 struct crd_ctx {
 	crd_params p{};
 	crd_grid g{};
@@ -91,6 +109,7 @@ struct crd_ctx {
 	double *err_partials = nullptr;  // adaptive stepping: per-item error sums (lazy)
 	int err_capacity = 0;
 
+	std::shared_ptr<StreamSet> streams;                               // owner of the handles below
 	hipStream_t compute = nullptr, comm = nullptr, band = nullptr;
 	bool bands_on_own_stream = true;  // CRD_BAND_STREAM=0: launch the edge bands on the compute stream, ahead of the interior
 	hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
@@ -541,13 +560,18 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 		                                       std::string(#expr) + ": " + hipGetErrorString(e_)));     \
 	} while (0)
 
-	CREATE_TRY(hipStreamCreateWithFlags(&c->compute, hipStreamNonBlocking));
-	CREATE_TRY(hipStreamCreateWithFlags(&c->comm, hipStreamNonBlocking));
+	c->streams = std::make_shared<StreamSet>();
+	c->streams->device = device;
+	CREATE_TRY(hipStreamCreateWithFlags(&c->streams->compute, hipStreamNonBlocking));
+	CREATE_TRY(hipStreamCreateWithFlags(&c->streams->comm, hipStreamNonBlocking));
 	{
 		int lo = 0, hi = 0;  // the band launch is tiny and on the critical path of the exchange: give it priority over the interior sweep
 		CREATE_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-		CREATE_TRY(hipStreamCreateWithPriority(&c->band, hipStreamNonBlocking, hi));
+		CREATE_TRY(hipStreamCreateWithPriority(&c->streams->band, hipStreamNonBlocking, hi));
 	}
+	c->compute = c->streams->compute;
+	c->comm = c->streams->comm;
+	c->band = c->streams->band;
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_interior, hipEventDisableTiming));
@@ -608,9 +632,7 @@ void crd_destroy(crd_ctx *c)
 	for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
 	for (hipEvent_t e : {c->ev_edges, c->ev_halo, c->ev_interior, c->ev_t0, c->ev_t1})
 		if (e) (void)hipEventDestroy(e);
-	if (c->compute) (void)hipStreamDestroy(c->compute);
-	if (c->comm) (void)hipStreamDestroy(c->comm);
-	if (c->band) (void)hipStreamDestroy(c->band);
+	c->streams.reset();  // destroys the streams unless another context of a LOCAL group on this device still uses them
 	// detach from a LOCAL group so the survivors do not dereference this context
 	for (crd_ctx *o : c->group)
 		if (o && o != c) {
@@ -644,6 +666,16 @@ int crd_comm_attach_local(crd_ctx *const *ctxs, int n)
 		if (c->p.precision != ctxs[0]->p.precision || c->nx != ctxs[0]->nx) return fail(ctxs[0], CRD_EINVAL, "contexts of one run must share nx and precision");
 		c->group.assign(ctxs, ctxs + n);
 		c->halo = CRD_HALO_LOCAL;
+		for (int j = 0; j < k; j++)
+			if (ctxs[j]->device == c->device) {  // slabs on one device run on one set of streams
+				if (hipSetDevice(c->device) != hipSuccess) return fail(ctxs[0], CRD_EHIP, "hipSetDevice failed");
+				for (hipStream_t s : {c->compute, c->comm, c->band}) (void)hipStreamSynchronize(s);
+				c->streams = ctxs[j]->streams;
+				c->compute = c->streams->compute;
+				c->comm = c->streams->comm;
+				c->band = c->streams->band;
+				break;
+			}
 	}
 	// enable peer access between distinct devices (ignore "already enabled")
 	for (int a = 0; a < n; a++)
