@@ -111,7 +111,10 @@ struct crd_ctx {
 
 	std::shared_ptr<StreamSet> streams;                               // owner of the handles below
 	hipStream_t compute = nullptr, comm = nullptr, band = nullptr;
-	bool bands_on_own_stream = true;  // CRD_BAND_STREAM=0: launch the edge bands on the compute stream, ahead of the interior
+	// Edge bands are launched on the compute stream ahead of the interior sweep.  CRD_BAND_STREAM=1 moves them to a third,
+	// high-priority stream (measured on one GPU with an RCCL self-ring: no gain at 8192 x 1024..4096 slabs, and the time then
+	// depends on when the runtime maps that stream to a hardware queue), kept as a knob for multi-GPU experiments.
+	bool bands_on_own_stream = false;
 	hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
 	std::vector<hipEvent_t> ev_k;  // per-launch timing events
 
@@ -363,6 +366,19 @@ int staged_step_multi(crd_ctx *const *cs, int n, double t, double dt, bool timed
 constexpr int kFusedBand = 32;
 static_assert(kFusedBand >= kGhost, "the edge bands must contain every row the exchange sends");
 
+// The edge-band stream exists only in contexts that step a multi-slab run with the fused stepper; it is created on first use.
+int ensure_band_stream(crd_ctx *c)
+{
+	if (c->band || !c->bands_on_own_stream) return CRD_OK;
+	if (!c->streams->band) {
+		int lo = 0, hi = 0;  // the band launch is tiny and on the critical path of the exchange: give it priority over the interior sweep
+		HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+		HIP_TRY(c, hipStreamCreateWithPriority(&c->streams->band, hipStreamNonBlocking, hi));
+	}
+	c->band = c->streams->band;
+	return CRD_OK;
+}
+
 int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, bool timed_step)
 {
 	const int ext = kStepHalo * (kExchangeEvery - 1 - q);
@@ -394,6 +410,7 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 		if (int rc = set_device(c)) return rc;
 		const FusedCall call = make_fused_call(c, t, dt, src, dst);
 		const bool split = c->nyl >= 4 * kFusedBand;
+		if (int rc = ensure_band_stream(c)) return rc;
 		hipStream_t bs = c->bands_on_own_stream ? c->band : c->compute;
 		if (kExchangeEvery == 1) {  // per-step exchange: this step's inputs were produced by the previous split step
 			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));
@@ -564,14 +581,8 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	c->streams->device = device;
 	CREATE_TRY(hipStreamCreateWithFlags(&c->streams->compute, hipStreamNonBlocking));
 	CREATE_TRY(hipStreamCreateWithFlags(&c->streams->comm, hipStreamNonBlocking));
-	{
-		int lo = 0, hi = 0;  // the band launch is tiny and on the critical path of the exchange: give it priority over the interior sweep
-		CREATE_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
-		CREATE_TRY(hipStreamCreateWithPriority(&c->streams->band, hipStreamNonBlocking, hi));
-	}
 	c->compute = c->streams->compute;
 	c->comm = c->streams->comm;
-	c->band = c->streams->band;
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_interior, hipEventDisableTiming));
@@ -669,11 +680,12 @@ int crd_comm_attach_local(crd_ctx *const *ctxs, int n)
 		for (int j = 0; j < k; j++)
 			if (ctxs[j]->device == c->device) {  // slabs on one device run on one set of streams
 				if (hipSetDevice(c->device) != hipSuccess) return fail(ctxs[0], CRD_EHIP, "hipSetDevice failed");
-				for (hipStream_t s : {c->compute, c->comm, c->band}) (void)hipStreamSynchronize(s);
+				for (hipStream_t s : {c->compute, c->comm, c->band})
+					if (s) (void)hipStreamSynchronize(s);
 				c->streams = ctxs[j]->streams;
 				c->compute = c->streams->compute;
 				c->comm = c->streams->comm;
-				c->band = c->streams->band;
+				c->band = nullptr;  // picked up from the shared set on first use
 				break;
 			}
 	}
@@ -1010,7 +1022,7 @@ int crd_synchronize(crd_ctx *c)
 	if (!c) return CRD_EINVAL;
 	if (int rc = set_device(c)) return rc;
 	HIP_TRY(c, hipStreamSynchronize(c->comm));
-	HIP_TRY(c, hipStreamSynchronize(c->band));
+	if (c->band) HIP_TRY(c, hipStreamSynchronize(c->band));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));
 	return CRD_OK;
 }

@@ -26,6 +26,6 @@ for ny in (1024, 2048, 4096):
         for _ in range(5):
             ms, _, _ = slab.step_rk4_timed(0.0, dt, steps)
             ts.append(ms / steps)
-        print("ny=%d %-4s band_stream=%s  %.2f us/step  (%.3e pt-steps/s)" % (ny, mode, os.environ.get("CRD_BAND_STREAM", "1"), statistics.median(ts) * 1e3,
+        print("ny=%d %-4s band_stream=%s  %.2f us/step  (%.3e pt-steps/s)" % (ny, mode, os.environ.get("CRD_BAND_STREAM", "0"), statistics.median(ts) * 1e3,
                                                                           nx * ny / (statistics.median(ts) * 1e-3)), flush=True)
         slab.close()
