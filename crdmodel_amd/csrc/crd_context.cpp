@@ -629,7 +629,8 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 void crd_destroy(crd_ctx *c)
 {
 	if (!c) return;
-	(void)hipSetDevice(c->device);
+	if (c->streams) (void)hipSetDevice(c->device);  // a context refused at creation (e.g. bad device ordinal) owns nothing on any device
+	(void)hipGetLastError();
 	if (c->compute) (void)hipStreamSynchronize(c->compute);
 	if (c->comm) (void)hipStreamSynchronize(c->comm);
 	if (c->band) (void)hipStreamSynchronize(c->band);

@@ -12,6 +12,12 @@ namespace dev {
 
 constexpr int kNumXcd = 8;
 
+// Status of the launch just made.  HIP keeps the last error of ANY earlier call on this thread until it is read, so the
+// launchers clear it before launching (clear_launch_status) and read it after: a stale error from an unrelated, already
+// handled failure (e.g. a refused crd_create) must not be pinned on a later, successful launch.
+inline void clear_launch_status() { (void)hipGetLastError(); }
+inline hipError_t launch_status() { return hipGetLastError(); }
+
 template <typename Real> struct Pair;
 template <> struct Pair<double> { using type = double2; };
 template <> struct Pair<float> { using type = float2; };

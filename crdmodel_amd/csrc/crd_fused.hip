@@ -342,6 +342,7 @@ template <typename Real, int MODEL>
 hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, int js, int ny,
                           hipStream_t st)
 {
+	clear_launch_status();
 	if (row_end <= row_begin) return hipSuccess;
 	if (row_end2 < row_begin2) row_end2 = row_begin2;
 	// rows may extend into the ghost region (deep-halo steps), but the pipeline reads kStepHalo rows beyond them
@@ -387,7 +388,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	} else {
 		crd_rk4_fused_step_kernel<Real, MODEL, false, false><<<nblocks, block, 0, st>>>(s, a);
 	}
-	return hipGetLastError();
+	return launch_status();
 }
 
 }  // namespace

@@ -229,6 +229,7 @@ inline int grid_for(size_t n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) 
 template <typename Real, int MODEL>
 hipError_t launch_stage_t(const SlabDesc &d, const StageCall &c, int row_begin, int row_end, hipStream_t st)
 {
+	clear_launch_status();
 	const Slab<Real> s = typed<Real>(d);
 	StageArgs<Real> a;
 	a.in_u = row0<Real>(c.yin.u, d.nx);
@@ -259,12 +260,13 @@ hipError_t launch_stage_t(const SlabDesc &d, const StageCall &c, int row_begin, 
 	case 4: crd_rk4_stage_kernel<Real, MODEL, 4><<<nblocks, block, 0, st>>>(s, a, row_begin, row_end, nbx, nblocks); break;
 	default: return hipErrorInvalidValue;
 	}
-	return hipGetLastError();
+	return launch_status();
 }
 
 template <typename Real, int MODEL>
 hipError_t launch_rhs_aos_t(const SlabDesc &d, int absorb, const void *y, void *ydot, const void *glo, const void *ghi, hipStream_t st)
 {
+	clear_launch_status();
 	using P = typename Pair<Real>::type;
 	const Slab<Real> s = typed<Real>(d);
 	const int nbx = (d.nx + kTX - 1) / kTX, nby = (d.nyl + kTY - 1) / kTY;
@@ -272,7 +274,7 @@ hipError_t launch_rhs_aos_t(const SlabDesc &d, int absorb, const void *y, void *
 	crd_rhs_aos_kernel<Real, MODEL><<<nblocks, dim3(kTX, kBY), 0, st>>>(s, static_cast<const P *>(y), static_cast<P *>(ydot),
 	                                                                  static_cast<const Real *>(glo), static_cast<const Real *>(ghi), absorb, nbx,
 	                                                                  nblocks);
-	return hipGetLastError();
+	return launch_status();
 }
 
 }  // namespace
@@ -300,6 +302,7 @@ hipError_t launch_rhs_aos(int precision, const SlabDesc &d, int absorb, const vo
 
 hipError_t launch_aos_to_planes(int precision, int src_is_f64, const void *aos, Planes dst, int nx, int nyl, hipStream_t s)
 {
+	clear_launch_status();
 	const size_t n = (size_t)nx * (size_t)nyl;
 	if (n == 0) return hipSuccess;
 	const int g = grid_for(n);
@@ -311,11 +314,12 @@ hipError_t launch_aos_to_planes(int precision, int src_is_f64, const void *aos, 
 	} else {
 		crd_aos_to_planes_kernel<float, float><<<g, 256, 0, s>>>(static_cast<const float *>(aos), row0<float>(dst.u, nx), row0<float>(dst.v, nx), n);
 	}
-	return hipGetLastError();
+	return launch_status();
 }
 
 hipError_t launch_planes_to_aos(int precision, int dst_is_f64, Planes src, void *aos, int nx, int nyl, hipStream_t s)
 {
+	clear_launch_status();
 	const size_t n = (size_t)nx * (size_t)nyl;
 	if (n == 0) return hipSuccess;
 	const int g = grid_for(n);
@@ -327,21 +331,23 @@ hipError_t launch_planes_to_aos(int precision, int dst_is_f64, Planes src, void 
 	} else {
 		crd_planes_to_aos_kernel<float, float><<<g, 256, 0, s>>>(row0<float>(src.u, nx), row0<float>(src.v, nx), static_cast<float *>(aos), n);
 	}
-	return hipGetLastError();
+	return launch_status();
 }
 
 hipError_t launch_aos_row_extract(int precision, const void *aos, void *row, int nx, int j, hipStream_t s)
 {
+	clear_launch_status();
 	const int g = (nx + 255) / 256;
 	if (precision == CRD_PRECISION_F64)
 		crd_aos_row_extract_kernel<double><<<g, 256, 0, s>>>(static_cast<const double *>(aos) + 2 * (size_t)j * nx, static_cast<double *>(row), nx);
 	else
 		crd_aos_row_extract_kernel<float><<<g, 256, 0, s>>>(static_cast<const float *>(aos) + 2 * (size_t)j * nx, static_cast<float *>(row), nx);
-	return hipGetLastError();
+	return launch_status();
 }
 
 hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s)
 {
+	clear_launch_status();
 	const size_t n = (size_t)nx * (size_t)nyl;
 	hipError_t e = hipMemsetAsync(out_dev, 0, sizeof(double), s);
 	if (e != hipSuccess || n == 0) return e;
@@ -350,7 +356,7 @@ hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, d
 		crd_max_abs_kernel<double><<<g, 256, 0, s>>>(row0<double>(const_cast<void *>(u_plane), nx), n, out_dev);
 	else
 		crd_max_abs_kernel<float><<<g, 256, 0, s>>>(row0<float>(const_cast<void *>(u_plane), nx), n, out_dev);
-	return hipGetLastError();
+	return launch_status();
 }
 
 }  // namespace crd
