@@ -80,3 +80,33 @@ def test_driver_adaptive_mode(gpu_device, tmp_path):
     assert r.returncode == 0, r.stderr
     u2, meta2 = load_like_the_plot_script(out2, "FHNmodel_torus", "u")
     assert meta2["nprocs"] == 2 and rel_err(u2, want[..., 0]) <= 1e-9
+
+
+def test_config_c1_flat_256_driver(gpu_device, tmp_path):
+    """BASELINE config C1: FitzHugh-Nagumo on a 256 x 256 flat periodic grid through the reference's command line
+    (`FHNmodel_flat <ini>`, xMesh key as in the shipped data/FHNmodelArgs.ini, surfaceLength = surfaceWidth so ny = nx):
+    banner, file set and numbers against the oracle."""
+    ini = tmp_path / "c1.ini"
+    ini.write_text("[Parameters]\ndiffusion = 0.12\nbeta = 1.25\nsurfaceWidth = 20\t\nsurfaceLength = 20\nwaveLength = 0.1\nwaveWidth = 0.5\n"
+                   "outputTimestep = 4\ntBoundary = 0.3\ntFinal = 0.8\nxMesh = 256\nbetaMin = 0.7\nbetaMax = 1.7\n\n[System]\nincludeAllVars = 0\nvaryBeta = 0\n")
+    cfg = crd.load_ini(ini, "fhn", "flat")
+    g = crd.grid_of(cfg.params)
+    assert (g.nx, g.ny) == (256, 256)
+    r = subprocess.run([os.path.join(BIN, "FHNmodel_flat"), str(ini)], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "2D FHN model PDE problem on a flat surface:" in r.stdout and "Surface length = 20" in r.stdout and "Stable state values: U = -1.25, V = -1.79688" in r.stdout
+    files = sorted(f for f in os.listdir(tmp_path) if f.startswith("FHNmodel_flat"))
+    assert files == ["FHNmodel_flat_subdomain.000.txt", "FHNmodel_flat_u.000.txt", "FHNmodel_flat_v.000.txt"]
+    assert os.path.getsize(tmp_path / "FHNmodel_flat_v.000.txt") == 0  # includeAllVars = 0: created, left empty
+    p = cfg.params
+    op = co.make_problem(co.FHN, co.FLAT, 256, 20.0, 20.0, p.diffusion, p.beta, t_boundary=p.t_boundary)
+    y = co.initial_conditions(op, cfg.wave_length, cfg.wave_width, 0, 0)
+    d_tout = cfg.t_final / cfg.output_timestep
+    steps = int(np.ceil(d_tout / (cfg.dt_safety * crd.stable_dt(p)) - 1e-12))
+    frames = [y]
+    for k in range(cfg.output_timestep):
+        y = co.rk4(op, y, k * d_tout, d_tout / steps, steps, nthreads=4)
+        frames.append(y)
+    u, meta = load_like_the_plot_script(tmp_path, "FHNmodel_flat", "u")
+    assert (meta["nx"], meta["ny"], meta["nt"], meta["xmax"]) == (256, 256, 5, 20.0)
+    assert rel_err(u, np.stack(frames)[..., 0]) <= 1e-9
