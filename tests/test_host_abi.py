@@ -187,3 +187,39 @@ def test_stable_dt_bounds_the_diffusion_limit():
     for n, lim in ((4096, 1.25e-4), (8192, 3.1e-5)):
         dt = crd.stable_dt(crd.make_params("fhn", "torus", n, 80.0, 20.0, 0.12, 1.25, ny=n))
         assert 0.8 * lim < dt <= 1.02 * lim
+
+
+def test_header_is_plain_c_and_links_from_c(tmp_path):
+    """include/crd.h must be consumable by a C compiler (the reference's FFI would be cgo / ctypes / a C++ TU): compile a
+    C99 program against it with gcc -pedantic, link libcrd.so, and run the host-side entry points."""
+    import subprocess
+
+    src = tmp_path / "abi.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "crd.h"
+int main(void) {
+	crd_params p; crd_grid g; int64_t js, je; double s0, s1; crd_halo_op ops[4]; crd_adaptive_options ao;
+	memset(&p, 0, sizeof p);
+	p.model = CRD_MODEL_FHN; p.surface = CRD_SURFACE_TORUS; p.nx = 100; p.surface_length = 100.0; p.surface_width = 20.0;
+	p.diffusion = 0.12; p.beta = 1.25; p.precision = CRD_PRECISION_F64;
+	if (crd_abi_version() != CRD_ABI_VERSION) return 1;
+	if (crd_grid_from_params(&p, &g) != CRD_OK || g.ny != 499) return 2;
+	if (crd_slab_extents(g.ny, 3, 4, &js, &je) != CRD_OK || je != 498) return 3;
+	if (crd_steady_state(CRD_MODEL_FHN, 1.25, &s0, &s1) != CRD_OK || s0 != -1.25) return 4;
+	if (crd_halo_plan(0, 2, 64, 16, ops) != CRD_OK || ops[0].peer != 1 || ops[2].row_begin != -16) return 5;
+	if (crd_adaptive_defaults(&ao) != CRD_OK || ao.rtol != 1e-5) return 6;
+	if (!(crd_stable_dt(&p) > 0.0)) return 7;
+	printf("%s %ld\n", crd_status_string(CRD_EPARSE), (long)sizeof(crd_run_config));
+	return 0;
+}
+''')
+    exe = tmp_path / "abi"
+    libdir = os.path.join(ROOT, "crdmodel_amd")
+    subprocess.run(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L", libdir, "-lcrd",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
+    r = subprocess.run([str(exe)], capture_output=True, text=True)
+    assert r.returncode == 0, (r.returncode, r.stderr)
+    assert r.stdout.split()[:3] == ["ini", "parse", "error"]
+    assert int(r.stdout.split()[-1]) == C.sizeof(crd._capi.RunConfig)  # the ctypes mirror has the C layout
