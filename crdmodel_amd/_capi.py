@@ -107,6 +107,8 @@ _SIGNATURES = {
     "crd_halo_plan": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(HaloOp)]),
     "crd_state_upload": (C.c_int, [_vp, _vp, C.c_int]),
     "crd_state_download": (C.c_int, [_vp, _vp, C.c_int]),
+    "crd_host_alloc": (_vp, [C.c_size_t]),
+    "crd_host_free": (None, [_vp]),
     "crd_rhs_host": (C.c_int, [_vp, C.c_double, _vp, _vp]),
     "crd_rhs_device": (C.c_int, [_vp, C.c_double, _vp, _vp]),
     "crd_set_stepper": (C.c_int, [_vp, C.c_int]),

@@ -117,6 +117,8 @@ struct crd_ctx {
 	bool bands_on_own_stream = false;
 	hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
 	std::vector<hipEvent_t> ev_k;  // per-launch timing events
+	hipStream_t down = nullptr;    // device-to-host stream of the pipelined crd_rhs_host (lazy)
+	std::vector<hipEvent_t> ev_band;  // its per-band events (lazy)
 
 	SlabDesc desc{};
 	int stepper = CRD_STEPPER_AUTO;
@@ -642,6 +644,11 @@ void crd_destroy(crd_ctx *c)
 	                (void *)c->err_partials})
 		if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
+	for (hipEvent_t e : c->ev_band) (void)hipEventDestroy(e);
+	if (c->down) {
+		(void)hipStreamSynchronize(c->down);
+		(void)hipStreamDestroy(c->down);
+	}
 	for (hipEvent_t e : {c->ev_edges, c->ev_halo, c->ev_interior, c->ev_t0, c->ev_t1})
 		if (e) (void)hipEventDestroy(e);
 	c->streams.reset();  // destroys the streams unless another context of a LOCAL group on this device still uses them
@@ -775,8 +782,85 @@ int crd_rhs_device(crd_ctx *c, double t, const void *y, void *ydot)
 		}
 		NCCL_TRY(c, g_rccl.GroupEnd());
 	}
-	HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorbing(c, t) ? 1 : 0, y, ydot, c->ghost_lo, c->ghost_hi, c->compute));
+	HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorbing(c, t) ? 1 : 0, y, ydot, c->ghost_lo, c->ghost_hi, 0, c->nyl, c->compute));
 	return CRD_OK;
+}
+
+namespace {
+
+bool is_pinned_host(const void *p)
+{
+	hipPointerAttribute_t attr;
+	const hipError_t e = hipPointerGetAttributes(&attr, p);
+	(void)hipGetLastError();  // ordinary (pageable) host memory is reported as an error
+	return e == hipSuccess && attr.type == hipMemoryTypeHost;
+}
+
+// crd_rhs_host on pinned vectors, single slab: bands of rows flow host -> device -> kernel -> host with the three legs
+// of neighbouring bands overlapping (upload on the comm stream, kernels on the compute stream, download on its own stream).
+int rhs_host_pipelined(crd_ctx *c, double t, const void *y, void *ydot)
+{
+	const size_t row_bytes = 2 * (size_t)c->nx * c->real_size;
+	int band = (int)std::max<size_t>(64, ((size_t)32 << 20) / row_bytes);  // ~32 MiB per band
+	if (band > c->nyl) band = c->nyl;
+	const int nb = (c->nyl + band - 1) / band;
+	if (!c->down) HIP_TRY(c, hipStreamCreateWithFlags(&c->down, hipStreamNonBlocking));
+	while ((int)c->ev_band.size() < 2 * nb + 2) {
+		hipEvent_t e;
+		HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+		c->ev_band.push_back(e);
+	}
+	const char *src = static_cast<const char *>(y);
+	char *dst = static_cast<char *>(ydot);
+	char *din = static_cast<char *>(c->stage_in), *dout = static_cast<char *>(c->stage_out);
+	const int absorb = absorbing(c, t) ? 1 : 0;
+	// every stream starts behind whatever the context did before
+	HIP_TRY(c, hipEventRecord(c->ev_band[(size_t)(2 * nb)], c->compute));
+	HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_band[(size_t)(2 * nb)], 0));
+	HIP_TRY(c, hipStreamWaitEvent(c->down, c->ev_band[(size_t)(2 * nb)], 0));
+	// the periodic neighbour of row 0 is the last row: it goes first
+	HIP_TRY(c, hipMemcpyAsync(din + (size_t)(c->nyl - 1) * row_bytes, src + (size_t)(c->nyl - 1) * row_bytes, row_bytes, hipMemcpyHostToDevice, c->comm));
+	for (int k = 0; k < nb; k++) {
+		const int r0 = k * band, r1 = std::min(c->nyl, r0 + band);
+		HIP_TRY(c, hipMemcpyAsync(din + (size_t)r0 * row_bytes, src + (size_t)r0 * row_bytes, (size_t)(r1 - r0) * row_bytes, hipMemcpyHostToDevice, c->comm));
+		HIP_TRY(c, hipEventRecord(c->ev_band[(size_t)k], c->comm));
+		if (k >= 1) {  // band k-1 has its upper neighbour row now
+			const int q0 = (k - 1) * band, q1 = q0 + band;
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_band[(size_t)k], 0));
+			HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorb, din, dout, c->ghost_lo, c->ghost_hi, q0, q1, c->compute));
+			HIP_TRY(c, hipEventRecord(c->ev_band[(size_t)(nb + k - 1)], c->compute));
+			HIP_TRY(c, hipStreamWaitEvent(c->down, c->ev_band[(size_t)(nb + k - 1)], 0));
+			HIP_TRY(c, hipMemcpyAsync(dst + (size_t)q0 * row_bytes, dout + (size_t)q0 * row_bytes, (size_t)(q1 - q0) * row_bytes, hipMemcpyDeviceToHost, c->down));
+		}
+	}
+	{  // last band: its upper neighbour is row 0, uploaded with band 0
+		const int q0 = (nb - 1) * band, q1 = c->nyl;
+		HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_band[(size_t)(nb - 1)], 0));
+		HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorb, din, dout, c->ghost_lo, c->ghost_hi, q0, q1, c->compute));
+		HIP_TRY(c, hipEventRecord(c->ev_band[(size_t)(2 * nb - 1)], c->compute));
+		HIP_TRY(c, hipStreamWaitEvent(c->down, c->ev_band[(size_t)(2 * nb - 1)], 0));
+		HIP_TRY(c, hipMemcpyAsync(dst + (size_t)q0 * row_bytes, dout + (size_t)q0 * row_bytes, (size_t)(q1 - q0) * row_bytes, hipMemcpyDeviceToHost, c->down));
+	}
+	HIP_TRY(c, hipStreamSynchronize(c->down));
+	HIP_TRY(c, hipStreamSynchronize(c->compute));
+	return CRD_OK;
+}
+
+}  // namespace
+
+void *crd_host_alloc(size_t bytes)
+{
+	void *p = nullptr;
+	if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault) != hipSuccess) {
+		(void)hipGetLastError();
+		return nullptr;
+	}
+	return p;
+}
+
+void crd_host_free(void *p)
+{
+	if (p) (void)hipHostFree(p);
 }
 
 int crd_rhs_host(crd_ctx *c, double t, const void *y, void *ydot)
@@ -785,6 +869,7 @@ int crd_rhs_host(crd_ctx *c, double t, const void *y, void *ydot)
 	if (int rc = set_device(c)) return rc;
 	const size_t bytes = 2 * (size_t)c->nx * (size_t)c->nyl * c->real_size;
 	if (int rc = ensure_staging(c, 2 * (size_t)c->nx * (size_t)c->nyl * 8)) return rc;
+	if (c->halo == CRD_HALO_SELF && c->nyl >= 128 && is_pinned_host(y) && is_pinned_host(ydot)) return rhs_host_pipelined(c, t, y, ydot);
 	HIP_TRY(c, hipMemcpyAsync(c->stage_in, y, bytes, hipMemcpyHostToDevice, c->compute));
 	if (int rc = crd_rhs_device(c, t, c->stage_in, c->stage_out)) return rc;
 	HIP_TRY(c, hipMemcpyAsync(ydot, c->stage_out, bytes, hipMemcpyDeviceToHost, c->compute));
@@ -815,7 +900,7 @@ int crd_group_rhs_device(crd_ctx *const *ctxs, int n, double t, const void *cons
 		HIP_TRY(c, hipStreamWaitEvent(c->compute, next->ev_edges, 0));
 		HIP_TRY(c, hipMemcpyPeerAsync(c->ghost_lo, c->device, prev->edge_hi, prev->device, bytes, c->compute));
 		HIP_TRY(c, hipMemcpyPeerAsync(c->ghost_hi, c->device, next->edge_lo, next->device, bytes, c->compute));
-		HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorbing(c, t) ? 1 : 0, y[k], ydot[k], c->ghost_lo, c->ghost_hi, c->compute));
+		HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorbing(c, t) ? 1 : 0, y[k], ydot[k], c->ghost_lo, c->ghost_hi, 0, c->nyl, c->compute));
 	}
 	// the edge buffers may be repacked by the next call only after every neighbour has copied them
 	for (int k = 0; k < n; k++) {

@@ -44,9 +44,10 @@ struct StageCall {
 };
 
 // One evaluation of f on AoS device vectors (the ARKRhsFn boundary): y, ydot are [nyl][nx][2];
-// ghost_lo / ghost_hi hold var0 of rows -1 and nyl (ignored when d.wrap).
+// ghost_lo / ghost_hi hold var0 of rows -1 and nyl (ignored when d.wrap).  Rows [row_begin, row_end) are produced; rows
+// row_begin-1 and row_end of y must be resident as well (the pipelined host path computes band by band).
 hipError_t launch_rhs_aos(int precision, const SlabDesc &d, int absorb, const void *y, void *ydot, const void *ghost_lo,
-                          const void *ghost_hi, hipStream_t s);
+                          const void *ghost_hi, int row_begin, int row_end, hipStream_t s);
 
 // One RK4 stage (or a bare RHS) on SoA planes, rows [row_begin, row_end) of the slab.
 hipError_t launch_stage(int precision, const SlabDesc &d, const StageCall &c, int row_begin, int row_end, hipStream_t s);

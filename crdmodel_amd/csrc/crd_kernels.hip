@@ -121,7 +121,8 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, S
 template <typename Real, int MODEL>
 __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, const typename Pair<Real>::type *__restrict__ y,
                                                                typename Pair<Real>::type *__restrict__ ydot, const Real *__restrict__ ghost_lo,
-                                                               const Real *__restrict__ ghost_hi, int absorb, int nbx, int nblocks)
+                                                               const Real *__restrict__ ghost_hi, int absorb, int row_begin, int row_end, int nbx,
+                                                               int nblocks)
 {
 	using P = typename Pair<Real>::type;
 	__shared__ Real tile[kTY + 2][kTX + 2];
@@ -131,7 +132,7 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, con
 	const int tx = threadIdx.x, ty = threadIdx.y;
 	const int nx = s.nx, nyl = s.nyl;
 	const int i0 = bx * kTX, i = i0 + tx;
-	const int j0 = by * kTY;
+	const int j0 = row_begin + by * kTY;  // rows [row_begin, row_end) of the slab; their phi neighbours must be resident too
 	const bool col_ok = i < nx;
 	const int iw = (i0 == 0) ? nx - 1 : i0 - 1;
 	const bool last_col = col_ok && (tx == kTX - 1 || i == nx - 1);
@@ -142,16 +143,16 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, con
 	for (int r = 0; r < kRPT; r++) {
 		const int j = j0 + ty + kBY * r;
 		own[r].x = own[r].y = (Real)0;
-		if (j < nyl && col_ok) {
+		if (j < row_end && col_ok) {
 			const P *row = y + (size_t)j * nx;
 			own[r] = row[i];
 			if (tx == 0) tile[ty + kBY * r + 1][0] = row[iw].x;
 			if (last_col) tile[ty + kBY * r + 1][tx + 2] = row[ie].x;
 		}
-		if (j < nyl && col_ok) tile[ty + kBY * r + 1][tx + 1] = own[r].x;
+		if (j < row_end && col_ok) tile[ty + kBY * r + 1][tx + 1] = own[r].x;
 	}
 	if (ty < 2 && col_ok) {
-		const int jt = (ty == 0) ? j0 - 1 : ((j0 + kTY < nyl) ? j0 + kTY : nyl);
+		const int jt = (ty == 0) ? j0 - 1 : ((j0 + kTY < row_end) ? j0 + kTY : row_end);
 		const int tr = (ty == 0) ? 0 : jt - j0 + 1;
 		Real val;
 		if (jt >= 0 && jt < nyl) val = y[(size_t)jt * nx + i].x;
@@ -166,7 +167,7 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, con
 #pragma unroll
 	for (int r = 0; r < kRPT; r++) {
 		const int j = j0 + ty + kBY * r;
-		if (!(j < nyl && col_ok)) continue;
+		if (!(j < row_end && col_ok)) continue;
 		const int tr = ty + kBY * r + 1;
 		const bool zero = absorb && ((s.has_row0 && j == 0) || (s.has_rowN && j == nyl - 1));
 		P k;
@@ -264,16 +265,18 @@ hipError_t launch_stage_t(const SlabDesc &d, const StageCall &c, int row_begin, 
 }
 
 template <typename Real, int MODEL>
-hipError_t launch_rhs_aos_t(const SlabDesc &d, int absorb, const void *y, void *ydot, const void *glo, const void *ghi, hipStream_t st)
+hipError_t launch_rhs_aos_t(const SlabDesc &d, int absorb, const void *y, void *ydot, const void *glo, const void *ghi, int row_begin, int row_end,
+                            hipStream_t st)
 {
 	clear_launch_status();
+	if (row_end <= row_begin) return hipSuccess;
 	using P = typename Pair<Real>::type;
 	const Slab<Real> s = typed<Real>(d);
-	const int nbx = (d.nx + kTX - 1) / kTX, nby = (d.nyl + kTY - 1) / kTY;
+	const int nbx = (d.nx + kTX - 1) / kTX, nby = (row_end - row_begin + kTY - 1) / kTY;
 	const int nblocks = nbx * nby;
 	crd_rhs_aos_kernel<Real, MODEL><<<nblocks, dim3(kTX, kBY), 0, st>>>(s, static_cast<const P *>(y), static_cast<P *>(ydot),
-	                                                                  static_cast<const Real *>(glo), static_cast<const Real *>(ghi), absorb, nbx,
-	                                                                  nblocks);
+	                                                                  static_cast<const Real *>(glo), static_cast<const Real *>(ghi), absorb, row_begin,
+	                                                                  row_end, nbx, nblocks);
 	return launch_status();
 }
 
@@ -291,13 +294,13 @@ hipError_t launch_stage(int precision, const SlabDesc &d, const StageCall &c, in
 const char *stage_kernel_name(int, int) { return "crd_rk4_stage_kernel"; }
 
 hipError_t launch_rhs_aos(int precision, const SlabDesc &d, int absorb, const void *y, void *ydot, const void *ghost_lo, const void *ghost_hi,
-                          hipStream_t s)
+                          int row_begin, int row_end, hipStream_t s)
 {
 	if (precision == CRD_PRECISION_F64)
-		return d.model == CRD_MODEL_FHN ? launch_rhs_aos_t<double, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, s)
-		                                : launch_rhs_aos_t<double, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, s);
-	return d.model == CRD_MODEL_FHN ? launch_rhs_aos_t<float, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, s)
-	                                : launch_rhs_aos_t<float, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, s);
+		return d.model == CRD_MODEL_FHN ? launch_rhs_aos_t<double, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s)
+		                                : launch_rhs_aos_t<double, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s);
+	return d.model == CRD_MODEL_FHN ? launch_rhs_aos_t<float, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s)
+	                                : launch_rhs_aos_t<float, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s);
 }
 
 hipError_t launch_aos_to_planes(int precision, int src_is_f64, const void *aos, Planes dst, int nx, int nyl, hipStream_t s)

@@ -193,11 +193,13 @@ class Slab:
         return y
 
     # -- the RHS callback --------------------------------------------------------------------------------------
-    def f(self, t, y):
-        """ydot = f(t, y) for this slab's AoS vector (host arrays in the device precision)."""
+    def f(self, t, y, out=None):
+        """ydot = f(t, y) for this slab's AoS vector (host arrays in the device precision).  With y and `out` both over
+        pinned memory (PinnedArray) the call streams the slab band by band over the host link."""
         y = np.ascontiguousarray(y, dtype=self.dtype)
         assert y.shape == (self.nyl, self.nx, 2)
-        ydot = np.empty_like(y)
+        ydot = np.empty_like(y) if out is None else out
+        assert ydot.shape == y.shape and ydot.dtype == y.dtype and ydot.flags["C_CONTIGUOUS"]
         self._check(lib().crd_rhs_host(self._h, t, y.ctypes.data, ydot.ctypes.data), "crd_rhs_host")
         return ydot
 
@@ -242,6 +244,29 @@ class Slab:
     def init_rccl(self, unique_id):
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(lib().crd_comm_init_rccl(self._h, buf), "crd_comm_init_rccl")
+
+
+class PinnedArray:
+    """A numpy array over page-locked host memory from crd_host_alloc (freed with the object)."""
+
+    def __init__(self, shape, dtype=np.float64):
+        self.nbytes = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        self._p = lib().crd_host_alloc(self.nbytes)
+        if not self._p:
+            raise MemoryError("crd_host_alloc(%d) failed" % self.nbytes)
+        self.array = np.frombuffer((C.c_char * self.nbytes).from_address(self._p), dtype=dtype).reshape(shape)
+
+    def close(self):
+        if self._p:
+            self.array = None
+            lib().crd_host_free(self._p)
+            self._p = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def rccl_unique_id():

@@ -185,6 +185,13 @@ int crd_halo_plan(int slab, int n_slabs, int64_t nyl, int depth, crd_halo_op ops
 int crd_state_upload(crd_ctx *ctx, const void *y_aos_host, int host_is_f64);
 int crd_state_download(crd_ctx *ctx, void *y_aos_host, int host_is_f64);
 
+/* Page-locked host memory for the vectors handed to crd_rhs_host (e.g. as the data array of N_VMake_Parallel).  With
+ * pinned y and ydot a single-slab crd_rhs_host streams the slab band by band -- upload of band k+1, kernel on band k and
+ * download of band k-1 overlap, both directions of the host link busy -- instead of copy, compute, copy; pageable
+ * vectors work too, at the rate of a staged copy each way.  NULL when the allocation fails. */
+void *crd_host_alloc(size_t bytes);
+void crd_host_free(void *p);
+
 /* One RHS evaluation, the ARKRhsFn `f(t, y, ydot, user_data)` of src/FHNmodel_torus.cpp:126,504-667 (and
  * siblings): halo exchange + diffusion + kinetics, writes every element of ydot, does not modify y.
  * y / ydot are this slab's AoS vectors in the device precision; *_host takes host pointers (staged through

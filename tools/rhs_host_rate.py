@@ -19,7 +19,19 @@ for n in (4096, 8192):
         for _ in range(reps):
             s.f(0.0, y)
         el = (time.perf_counter() - t0) / reps
-        print("%dx%d crd_rhs_host: %.1f ms per call = %.3e point-RHS/s, %.1f GB/s over the host link (32 B/pt each way)" % (n, n, el * 1e3, n * n / el, 64.0 * n * n / el / 1e9))
+        print("%dx%d crd_rhs_host, pageable vectors: %.1f ms per call = %.3e point-RHS/s, %.1f GB/s over the host link (16 B/pt each way, one after the other)" % (n, n, el * 1e3, n * n / el, 32.0 * n * n / el / 1e9))
+        py, pd = crd.PinnedArray(y.shape), crd.PinnedArray(y.shape)
+        py.array[...] = y
+        ref = s.f(0.0, y)
+        s.f(0.0, py.array, out=pd.array)
+        assert np.array_equal(pd.array, ref)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            s.f(0.0, py.array, out=pd.array)
+        el = (time.perf_counter() - t0) / reps
+        print("%dx%d crd_rhs_host, pinned vectors (banded pipeline): %.1f ms per call = %.3e point-RHS/s, %.1f GB/s in each direction at once" % (n, n, el * 1e3, n * n / el, 16.0 * n * n / el / 1e9))
+        py.close()
+        pd.close()
         s.set_stepper("staged")
         s.upload(y)
         ms, kms, _ = s.step_rk4_timed(0.0, 1e-6, 20)
