@@ -59,20 +59,37 @@ inline Real *row0(void *plane, int nx)
 //   FHN        src/FHNmodel_torus.cpp:657,660
 //   Goldbeter  src/GoldbeterModel_torus.cpp:694-695,715-716 (pow(x,2), pow(x,4) as multiplies)
 //   absorbing  src/FHNmodel_torus.cpp:643-653 (zero = row is a global phi boundary row and t < TBOUNDARY)
+// Fused multiply-add, spelled out.  Implicit contraction is switched off for the kernels (pragma below): left to the
+// compiler, `a*b + c*d` may become fma(a,b,c*d) in one inlined copy of the point function and fma(c,d,a*b) in another, and
+// the same grid point then rounds differently depending on which pipeline slot or which slab computes it.  With every fma
+// explicit, a point's arithmetic is one fixed sequence: results are bit-identical across steppers' redundant recomputation,
+// slab decompositions and compiler versions.
+#pragma clang fp contract(off)
+__device__ __forceinline__ double fmadd(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float fmadd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
 template <typename Real, int MODEL>
 __device__ __forceinline__ void rhs_point(Real uC, Real uW, Real uE, Real uS, Real uN, Real v, Real cA, Real cX, Real cP, Real b,
                                           Real ka4, bool zero, bool just_diffusion, Real &du, Real &dv)
 {
-	const Real two = (Real)2;
-	const Real diff = cA * (uE - uW) + cX * ((uE - two * uC) + uW) + cP * ((uN - two * uC) + uS);
+	// second differences as the reference writes them, (uE - 2 uC + uW), so that a constant field diffuses to exactly zero
+	const Real d2x = fmadd((Real)-2, uC, uE) + uW;
+	const Real d2y = fmadd((Real)-2, uC, uN) + uS;
+	const Real diff = fmadd(cA, uE - uW, fmadd(cX, d2x, cP * d2y));
 	if (MODEL == CRD_MODEL_FHN) {
-		du = diff + (((Real)3.0 * uC - (uC * uC * uC)) - v);
+		const Real u3 = (uC * uC) * uC;
+		du = diff + (fmadd((Real)3.0, uC, -u3) - v);
 		dv = (Real)kFhnEpsilon * (uC + b);
 	} else {
+		// v2 = VM2 z^2 / (K2^2 + z^2), v3 = VM3 y^2 z^4 / ((KR^2 + y^2)(KA^4 + z^4)): one division for both Hill terms
+		// (a correctly rounded fp64 division costs ~15 instructions on this ISA, the three extra multiplies 3)
 		const Real z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
-		const Real v2 = (Real)kGbVm2 * z2 / ((Real)(kGbK2 * kGbK2) + z2);
-		const Real v3 = (Real)kGbVm3 * y2 * z4 / (((Real)(kGbKr * kGbKr) + y2) * (ka4 + z4));
-		du = diff + ((((((Real)kGbV0 + (Real)kGbV1 * b) - v2) + v3) + (Real)kGbKf * v) - (Real)kGbK * uC);
+		const Real dA = (Real)(kGbK2 * kGbK2) + z2, dB = ((Real)(kGbKr * kGbKr) + y2) * (ka4 + z4);
+		const Real rinv = (Real)1 / (dA * dB);
+		const Real v2 = ((Real)kGbVm2 * z2) * (dB * rinv);
+		const Real v3 = (((Real)kGbVm3 * y2) * z4) * (dA * rinv);
+		const Real src = fmadd((Real)kGbV1, b, (Real)kGbV0);  // v0 + v1 b
+		du = diff + fmadd(-(Real)kGbK, uC, ((src - v2) + v3) + (Real)kGbKf * v);
 		dv = (v2 - v3) - (Real)kGbKf * v;
 		if (just_diffusion) {  // src/GoldbeterModel_torus.cpp:668: the whole reaction block, absorbing rows included, is skipped
 			du = diff;

@@ -203,37 +203,37 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 			const int c = p - 1;
 			rhs_point<Real, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
 			                       ABSORB && a.absorb[0] && boundary_row(c), jd, du, dv);
-			U1[S1] = u0[S1] + a.h2 * du;
-			V1[S1 & 1] = v0[S1] + a.h2 * dv;
-			aU[S1] = u0[S1] + a.h6 * du;
-			aV[S1] = v0[S1] + a.h6 * dv;
+			U1[S1] = fmadd(a.h2, du, u0[S1]);
+			V1[S1 & 1] = fmadd(a.h2, dv, v0[S1]);
+			aU[S1] = fmadd(a.h6, du, u0[S1]);
+			aV[S1] = fmadd(a.h6, dv, v0[S1]);
 		}
 		// ---- stage 2, centre row p-2: y1 rows p-3, p-2, p-1 ---------------------------------------------------
 		if (!GUARDED || m >= 4) {
 			const int c = p - 2;
 			rhs_point<Real, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[S2 & 1], cA, cX, cP, bq[S2], ka4,
 			                       ABSORB && a.absorb[1] && boundary_row(c), jd, du, dv);
-			U2[S2] = u0[S2] + a.h2 * du;
-			V2[S2 & 1] = v0[S2] + a.h2 * dv;
-			aU[S2] += a.h3 * du;
-			aV[S2] += a.h3 * dv;
+			U2[S2] = fmadd(a.h2, du, u0[S2]);
+			V2[S2 & 1] = fmadd(a.h2, dv, v0[S2]);
+			aU[S2] = fmadd(a.h3, du, aU[S2]);
+			aV[S2] = fmadd(a.h3, dv, aV[S2]);
 		}
 		// ---- stage 3, centre row p-3: y2 rows p-4, p-3, p-2 ---------------------------------------------------
 		if (!GUARDED || m >= 6) {
 			const int c = p - 3;
 			rhs_point<Real, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[S3 & 1], cA, cX, cP, bq[S3], ka4,
 			                       ABSORB && a.absorb[2] && boundary_row(c), jd, du, dv);
-			U3[S3] = u0[S3] + a.h1 * du;
-			V3[S3 & 1] = v0[S3] + a.h1 * dv;
-			aU[S3] += a.h3 * du;
-			aV[S3] += a.h3 * dv;
+			U3[S3] = fmadd(a.h1, du, u0[S3]);
+			V3[S3 & 1] = fmadd(a.h1, dv, v0[S3]);
+			aU[S3] = fmadd(a.h3, du, aU[S3]);
+			aV[S3] = fmadd(a.h3, dv, aV[S3]);
 		}
 		// ---- stage 4, centre row p-4: y3 rows p-5, p-4, p-3 -> the new state ----------------------------------
 		if (!GUARDED || m >= 8) {
 			const int c = p - 4;
 			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
 			                       ABSORB && a.absorb[3] && boundary_row(c), jd, du, dv);
-			const Real nu = aU[S4] + a.h6 * du, nv = aV[S4] + a.h6 * dv;
+			const Real nu = fmadd(a.h6, du, aU[S4]), nv = fmadd(a.h6, dv, aV[S4]);
 			if ((EMBED ? (c >= j0 && c < j1) : c < j1) && lane_stores) {  // without the fifth stage c >= j0 holds from iteration 8 on
 				const ptrdiff_t o = (ptrdiff_t)c * nx + out_col;
 				a.out_u[o] = nu;
@@ -253,9 +253,9 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 			                       ABSORB && a.absorb[3] && boundary_row(c), jd, du, dv);  // k5 is evaluated at t + dt, like k4
 			if (lane_stores) {  // rows j0 .. j1-1 exactly: stage 5 starts at iteration 10 (row j0) and the loop ends at row j1-1
 				const Real au = u0[S5] < (Real)0 ? -u0[S5] : u0[S5], av = v0[S5] < (Real)0 ? -v0[S5] : v0[S5];
-				const Real eu = a.h6 * (K4U[S5 & 1] - du) / (a.rtol * au + a.atol);
-				const Real ev = a.h6 * (K4V[S5 & 1] - dv) / (a.rtol * av + a.atol);
-				err2 += eu * eu + ev * ev;
+				const Real eu = a.h6 * (K4U[S5 & 1] - du) / fmadd(a.rtol, au, a.atol);
+				const Real ev = a.h6 * (K4V[S5 & 1] - dv) / fmadd(a.rtol, av, a.atol);
+				err2 = fmadd(eu, eu, fmadd(ev, ev, err2));
 			}
 		}
 	};

@@ -101,18 +101,18 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, S
 			a.out_u[o] = du;
 			a.out_v[o] = dv;
 		} else if (STAGE == 1) {
-			a.out_u[o] = uC[r] + a.h_out * du;
-			a.out_v[o] = vC[r] + a.h_out * dv;
-			a.acc_u[o] = uC[r] + a.h_acc * du;
-			a.acc_v[o] = vC[r] + a.h_acc * dv;
+			a.out_u[o] = fmadd(a.h_out, du, uC[r]);
+			a.out_v[o] = fmadd(a.h_out, dv, vC[r]);
+			a.acc_u[o] = fmadd(a.h_acc, du, uC[r]);
+			a.acc_v[o] = fmadd(a.h_acc, dv, vC[r]);
 		} else if (STAGE == 2 || STAGE == 3) {
-			a.out_u[o] = p0u[r] + a.h_out * du;
-			a.out_v[o] = p0v[r] + a.h_out * dv;
-			a.acc_u[o] = pau[r] + a.h_acc * du;
-			a.acc_v[o] = pav[r] + a.h_acc * dv;
+			a.out_u[o] = fmadd(a.h_out, du, p0u[r]);
+			a.out_v[o] = fmadd(a.h_out, dv, p0v[r]);
+			a.acc_u[o] = fmadd(a.h_acc, du, pau[r]);
+			a.acc_v[o] = fmadd(a.h_acc, dv, pav[r]);
 		} else {
-			a.out_u[o] = pau[r] + a.h_acc * du;
-			a.out_v[o] = pav[r] + a.h_acc * dv;
+			a.out_u[o] = fmadd(a.h_acc, du, pau[r]);
+			a.out_v[o] = fmadd(a.h_acc, dv, pav[r]);
 		}
 	}
 }
