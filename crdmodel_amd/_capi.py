@@ -9,7 +9,8 @@ import os
 import sys
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libcrd.so")
+# CRD_LIBRARY points the binding at another build of the same ABI (tuning builds under tools/); default is the in-tree library.
+LIB_PATH = os.environ.get("CRD_LIBRARY") or os.path.join(_PKG, "libcrd.so")
 
 OK, EINVAL, ENOMEM, EHIP, ERCCL, EIO, EPARSE, ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
 MODEL_FHN, MODEL_GOLDBETER = 0, 1

@@ -389,20 +389,29 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			crd_ctx *c = cs[k];
 			if (int rc = set_device(c)) return rc;
 			const FusedCall call = make_fused_call(c, t, dt, src, dst);
-			if (q == 0) {  // first step after an exchange: the bands and the ghost rows of src come from other streams
-				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));
-				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
-				if (c->halo == CRD_HALO_LOCAL) {
-					// LOCAL halos are PULLED by the neighbours from this context's planes: the next step that overwrites those
-					// rows (q = 1) must not start before both neighbours have finished copying them
-					HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + c->n_slabs - 1) % c->n_slabs)]->ev_halo, 0));
-					HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + 1) % c->n_slabs)]->ev_halo, 0));
-				}
-			}
 			const bool timed = timed_step && !c->ev_k.empty();
-			if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
-			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
-			if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
+			if (q > 0) {
+				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
+				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
+				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
+				HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
+				continue;
+			}
+			// First step after an exchange.  Output rows [kStepHalo, nyl - kStepHalo) read owned rows only, so they are launched
+			// as soon as the bands of the previous step are in: the exchange gets this sweep as extra time to land.
+			const bool split = c->nyl >= 4 * kFusedBand;
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));
+			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kStepHalo, c->nyl - kStepHalo, 0, 0, c->compute));
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			if (c->halo == CRD_HALO_LOCAL) {
+				// LOCAL halos are PULLED by the neighbours from this context's planes: the next step that overwrites those
+				// rows (q = 1) must not start before both neighbours have finished copying them
+				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + c->n_slabs - 1) % c->n_slabs)]->ev_halo, 0));
+				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + 1) % c->n_slabs)]->ev_halo, 0));
+			}
+			// the rows that read ghost rows: [-ext, kStepHalo) and [nyl - kStepHalo, nyl + ext) in one launch
+			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, kStepHalo, c->nyl - kStepHalo, c->nyl + ext, c->compute));
+			else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
 			HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
 		}
 		return CRD_OK;
@@ -437,6 +446,8 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 }
 
 constexpr int kMaxTimedLaunches = 64;
+// Step of an exchange cycle whose single full-slab launch is the one timed in a multi-slab fused run (step 0 is split in two).
+constexpr int kTimedCycleStep = (kExchangeEvery > 2) ? 1 : 0;
 
 int ensure_timing_events(crd_ctx *c)
 {
@@ -491,9 +502,9 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			if (int rc = prime_halo(cs, n, crd_ctx::Y, fused ? kGhost : 1, fused)) return rc;
 		int cur = crd_ctx::Y;
 		for (int64_t s = 0; s < nsteps; s++) {
-			// time one launch of the dominant kernel mid-run (fused: a first-of-cycle step, the full-slab launch)
+			// time one launch of the dominant kernel mid-run (fused: the first one-launch step of a cycle)
 			const bool timed_step = timed_launches && !timed &&
-			                        (fused ? (s % kExchangeEvery == 0 && (s >= nsteps / 2 || s + kExchangeEvery >= nsteps)) : s >= nsteps / 2);
+			                        (fused ? (s % kExchangeEvery == kTimedCycleStep && (s >= nsteps / 2 || s + kExchangeEvery >= nsteps)) : s >= nsteps / 2);
 			const double t = t0 + (double)s * dt;
 			if (fused) {
 				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
@@ -561,7 +572,7 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	if (c->je - c->js + 1 > INT32_MAX / 2) return bail(fail(c, CRD_EINVAL, "slab too tall"));
 	c->nyl = (int)(c->je - c->js + 1);
 	if (c->nyl < 2 * kStepHalo) return bail(fail(c, CRD_EINVAL, "every slab needs at least 8 rows"));
-	if (n_slabs > 1 && c->nyl < kGhost) return bail(fail(c, CRD_EINVAL, "every slab of a multi-slab run needs at least 16 rows (one exchange moves 16 ghost rows)"));
+	if (n_slabs > 1 && c->nyl < kGhost) return bail(fail(c, CRD_EINVAL, "every slab of a multi-slab run needs at least " + std::to_string(kGhost) + " rows (one exchange moves that many ghost rows)"));
 	c->real_size = p->precision == CRD_PRECISION_F64 ? 8 : 4;
 	c->plane_bytes = (size_t)(c->nyl + 2 * kGhost) * (size_t)c->nx * c->real_size;
 	c->halo = n_slabs == 1 ? CRD_HALO_SELF : -1;  // multi-slab contexts must be wired before use
@@ -581,6 +592,9 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 
 	c->streams = std::make_shared<StreamSet>();
 	c->streams->device = device;
+	// Measured on a world-size-1 RCCL ring (tools/ring_overhead.py): leaving CUs out of the compute stream's CU mask to keep
+	// room for the exchange kernel costs 7-20% of the sweep, and a high-priority exchange stream changes nothing, so both
+	// streams are plain: the exchange kernel gets its CUs as the interior sweep drains and finishes under the next sweep.
 	CREATE_TRY(hipStreamCreateWithFlags(&c->streams->compute, hipStreamNonBlocking));
 	CREATE_TRY(hipStreamCreateWithFlags(&c->streams->comm, hipStreamNonBlocking));
 	c->compute = c->streams->compute;
@@ -1144,7 +1158,7 @@ int crd_dominant_kernel_rows(const crd_ctx *c, int64_t *rows)
 	if (!c || !rows) return CRD_EINVAL;
 	const int stepper = resolve_stepper(c);
 	if (c->halo == CRD_HALO_SELF) *rows = c->nyl;
-	else if (stepper == CRD_STEPPER_FUSED) *rows = c->nyl + 2 * kStepHalo * (kExchangeEvery - 1);  // the first step of an exchange cycle
+	else if (stepper == CRD_STEPPER_FUSED) *rows = c->nyl + 2 * kStepHalo * (kExchangeEvery - 1 - kTimedCycleStep);  // the timed step of an exchange cycle
 	else *rows = c->nyl - 2;
 	return CRD_OK;
 }

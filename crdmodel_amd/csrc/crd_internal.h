@@ -20,7 +20,11 @@ constexpr double kGbK2 = 1.0, kGbKr = 2.0, kGbKa = 0.9;
 constexpr int kStepHalo = 4;
 // Fused steps between two halo exchanges of a multi-slab run: the exchange moves kStepHalo * kExchangeEvery ghost rows and
 // each slab recomputes the shrinking ghost region redundantly in between (communication-avoiding deep halo).
-constexpr int kExchangeEvery = 4;
+#ifndef CRD_EXCHANGE_EVERY
+#define CRD_EXCHANGE_EVERY 4  // tuning builds override it with -DCRD_EXCHANGE_EVERY=n
+#endif
+constexpr int kExchangeEvery = CRD_EXCHANGE_EVERY;
+static_assert(kExchangeEvery >= 3, "the multi-slab fused stepper splits the first and the last step of a cycle");
 // Ghost rows kept above and below every slab plane.
 constexpr int kGhost = kStepHalo * kExchangeEvery;
 

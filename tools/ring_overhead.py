@@ -11,7 +11,7 @@ import crdmodel_amd as crd  # noqa: E402
 
 nx = int(os.environ.get("NX", "8192"))
 steps = int(os.environ.get("STEPS", "400"))
-for ny in (1024, 2048, 4096):
+for ny in [int(v) for v in os.environ.get("NYS", "1024,2048,4096").split(",")]:
     p = crd.make_params("fhn", "torus", nx, 80.0, 20.0, 0.12, 1.25, ny=ny)
     dt = 0.5 * crd.stable_dt(p)
     y0 = crd.initial_conditions(crd.run_config(p))
@@ -26,6 +26,6 @@ for ny in (1024, 2048, 4096):
         for _ in range(5):
             ms, _, _ = slab.step_rk4_timed(0.0, dt, steps)
             ts.append(ms / steps)
-        print("ny=%d %-4s band_stream=%s  %.2f us/step  (%.3e pt-steps/s)" % (ny, mode, os.environ.get("CRD_BAND_STREAM", "0"), statistics.median(ts) * 1e3,
-                                                                          nx * ny / (statistics.median(ts) * 1e-3)), flush=True)
+        knobs = " ".join("%s=%s" % (k[4:].lower(), v) for k, v in sorted(os.environ.items()) if k.startswith("CRD_"))
+        print("ny=%d %-4s [%s]  %.2f us/step  (%.3e pt-steps/s)" % (ny, mode, knobs, statistics.median(ts) * 1e3, nx * ny / (statistics.median(ts) * 1e-3)), flush=True)
         slab.close()
