@@ -1,0 +1,132 @@
+// crd_ctx.h -- the device context behind the C ABI and the helpers its translation units share (not part of the ABI):
+//   crd_context.cpp   lifecycle, communicator wiring, state transfer, the f() entry points
+//   crd_halo.cpp      RCCL binding and the halo transports
+//   crd_steppers.cpp  fixed-step RK4 drivers (staged / fused, single slab / deep-halo multi-slab) and the adaptive integrator
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>  // types and prototypes only; the library is bound with dlopen at first use
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "crd_internal.h"
+#include "crd_kernels.h"
+
+namespace crd {
+
+// RCCL is bound at first use, not at load time: single-GPU runs never map the library, and a process that already
+// carries an RCCL (PyTorch bundles one under the same SONAME) shares that copy instead of loading a second one.
+struct RcclApi {
+	void *handle = nullptr;
+	decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+	decltype(&ncclCommInitRank) CommInitRank = nullptr;
+	decltype(&ncclCommDestroy) CommDestroy = nullptr;
+	decltype(&ncclGroupStart) GroupStart = nullptr;
+	decltype(&ncclGroupEnd) GroupEnd = nullptr;
+	decltype(&ncclSend) Send = nullptr;
+	decltype(&ncclRecv) Recv = nullptr;
+	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclGetErrorString) GetErrorString = nullptr;
+	std::string error;
+
+	bool load();  // crd_halo.cpp
+};
+extern RcclApi g_rccl;
+
+}  // namespace crd
+
+// The three streams of a context: interior sweeps, edge bands (high priority), halo exchange.  Contexts of a LOCAL group
+// that share a device share one set (crd_comm_attach_local), so a device never carries more than three of this library's
+// streams however many slabs it hosts.
+struct StreamSet {
+	int device = 0;
+	hipStream_t compute = nullptr, comm = nullptr, band = nullptr;
+	~StreamSet()
+	{
+		(void)hipSetDevice(device);
+		for (hipStream_t s : {compute, comm, band})
+			if (s) {
+				(void)hipStreamSynchronize(s);
+				(void)hipStreamDestroy(s);
+			}
+	}
+};
+
+struct crd_ctx {
+	crd_params p{};
+	crd_grid g{};
+	int slab = 0, n_slabs = 1, device = 0;
+	int64_t js = 0, je = 0;
+	int nx = 0, nyl = 0;
+	size_t real_size = 8;
+	size_t plane_bytes = 0;
+
+	// State planes: Y (current), SA / SB (stage ping-pong), ACC; [k][0] = var0, [k][1] = var1.
+	enum { Y = 0, SA = 1, SB = 2, ACC = 3, NPLANES = 4 };
+	void *plane[NPLANES][2] = {};
+	void *cA = nullptr, *cP = nullptr, *brow = nullptr;
+	void *stage_in = nullptr, *stage_out = nullptr;  // AoS staging for the *_host entry points (lazy)
+	size_t stage_bytes = 0;
+	void *ghost_lo = nullptr, *ghost_hi = nullptr;   // var0 of rows -1 / nyl for the AoS RHS (multi-slab)
+	void *edge_lo = nullptr, *edge_hi = nullptr;     // var0 of rows 0 / nyl-1 packed from an AoS vector
+	double *scalar_dev = nullptr;
+	double *err_partials = nullptr;  // adaptive stepping: per-item error sums (lazy)
+	int err_capacity = 0;
+
+	std::shared_ptr<StreamSet> streams;                               // owner of the handles below
+	hipStream_t compute = nullptr, comm = nullptr, band = nullptr;
+	// Edge bands are launched on the compute stream ahead of the interior sweep.  CRD_BAND_STREAM=1 moves them to a third,
+	// high-priority stream (measured on one GPU with an RCCL self-ring: no gain at 8192 x 1024..4096 slabs, and the time then
+	// depends on when the runtime maps that stream to a hardware queue), kept as a knob for multi-GPU experiments.
+	bool bands_on_own_stream = false;
+	hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+	std::vector<hipEvent_t> ev_k;  // per-launch timing events
+	hipStream_t down = nullptr;    // device-to-host stream of the pipelined crd_rhs_host (lazy)
+	std::vector<hipEvent_t> ev_band;  // its per-band events (lazy)
+
+	crd::SlabDesc desc{};
+	int stepper = CRD_STEPPER_AUTO;
+
+	int halo = CRD_HALO_SELF;
+	std::vector<crd_ctx *> group;  // LOCAL: all contexts of the run, by slab index
+	ncclComm_t nccl = nullptr;
+
+	std::string err;
+
+	crd::Planes planes(int k) const { return crd::Planes{plane[k][0], plane[k][1]}; }
+	void *row_ptr(void *base, int64_t j) const { return static_cast<char *>(base) + (size_t)(j + crd::kGhost) * (size_t)nx * real_size; }
+};
+
+namespace crd {
+
+int fail(crd_ctx *c, int code, const std::string &msg);  // records msg (thread-local when c is null) and returns code
+
+#define HIP_TRY(ctx, expr)                                                                                      \
+	do {                                                                                                        \
+		hipError_t e_ = (expr);                                                                                 \
+		if (e_ != hipSuccess) return fail((ctx), CRD_EHIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+	} while (0)
+
+#define NCCL_TRY(ctx, expr)                                                                                        \
+	do {                                                                                                           \
+		ncclResult_t r_ = (expr);                                                                                  \
+		if (r_ != ncclSuccess) return fail((ctx), CRD_ERCCL, std::string(#expr) + ": " + g_rccl.GetErrorString(r_)); \
+	} while (0)
+int set_device(crd_ctx *c);
+int upload_table(crd_ctx *c, const std::vector<double> &src, void **dst);  // host doubles -> device precision
+int ensure_staging(crd_ctx *c, size_t bytes);                              // AoS staging of the *_host entry points
+inline bool absorbing(const crd_ctx *c, double t_stage) { return t_stage < c->p.t_boundary; }  // strict <, src/FHNmodel_torus.cpp:643
+int resolve_stepper(const crd_ctx *c);  // CRD_STEPPER_STAGED / _FUSED, or -1 when the requested one is unavailable
+int check_group(crd_ctx *const *ctxs, int n);
+
+// crd_halo.cpp: fill ghost rows [-depth, 0) and [nyl, nyl + depth) of plane `plane_index` from the ring neighbours, on the comm streams
+int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_v);
+int prime_halo(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_v);
+
+// crd_steppers.cpp
+FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int dst);
+int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, int *timed_launches);
+
+}  // namespace crd

@@ -1,0 +1,121 @@
+// crd_halo.cpp -- the RCCL binding and the halo transports of multi-slab runs.  Host code only.
+#include <dlfcn.h>
+
+#include "crd_ctx.h"
+
+namespace crd {
+
+RcclApi g_rccl;
+
+bool RcclApi::load()
+{
+	if (handle) return true;
+	if (!error.empty()) return false;
+	for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+		handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+		if (handle) break;
+	}
+	if (!handle) {
+		error = std::string("cannot load librccl: ") + dlerror();
+		return false;
+	}
+	auto sym = [&](const char *n) {
+		void *p = dlsym(handle, n);
+		if (!p && error.empty()) error = std::string("librccl lacks ") + n;
+		return p;
+	};
+	GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(sym("ncclGetUniqueId"));
+	CommInitRank = reinterpret_cast<decltype(CommInitRank)>(sym("ncclCommInitRank"));
+	CommDestroy = reinterpret_cast<decltype(CommDestroy)>(sym("ncclCommDestroy"));
+	GroupStart = reinterpret_cast<decltype(GroupStart)>(sym("ncclGroupStart"));
+	GroupEnd = reinterpret_cast<decltype(GroupEnd)>(sym("ncclGroupEnd"));
+	Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
+	Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
+	AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+	GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
+	if (!error.empty()) {
+		handle = nullptr;
+		return false;
+	}
+	return true;
+}
+
+namespace {
+
+// The two transports: fill the ghost rows [-depth, 0) and [nyl, nyl + depth) of one context's planes from its ring
+// neighbours, enqueued on the context's comm stream.
+
+// RCCL: the four point-to-point operations of crd_halo_plan per field, in one group.
+int exchange_rccl(crd_ctx *c, Planes pl, int depth, bool with_v)
+{
+	const size_t count = (size_t)depth * (size_t)c->nx;
+	const ncclDataType_t dt = c->p.precision == CRD_PRECISION_F64 ? ncclDouble : ncclFloat;
+	void *fields[2] = {pl.u, pl.v};
+	crd_halo_op ops[4];
+	if (crd_halo_plan(c->slab, c->n_slabs, c->nyl, depth, ops) != CRD_OK) return fail(c, CRD_EINVAL, "bad halo plan");
+	NCCL_TRY(c, g_rccl.GroupStart());
+	for (int f = 0; f < (with_v ? 2 : 1); f++)
+		for (const crd_halo_op &op : ops) {
+			void *rows = c->row_ptr(fields[f], op.row_begin);
+			if (op.is_send) NCCL_TRY(c, g_rccl.Send(rows, count, dt, op.peer, c->nccl, c->comm));
+			else NCCL_TRY(c, g_rccl.Recv(rows, count, dt, op.peer, c->nccl, c->comm));
+		}
+	NCCL_TRY(c, g_rccl.GroupEnd());
+	return CRD_OK;
+}
+
+// LOCAL: pull the rows from the neighbours' planes with device-to-device copies (peer copies across devices).
+int exchange_local_pull(crd_ctx *c, int plane_index, int depth, bool with_v)
+{
+	crd_ctx *prev = c->group[(size_t)((c->slab + c->n_slabs - 1) % c->n_slabs)];
+	crd_ctx *next = c->group[(size_t)((c->slab + 1) % c->n_slabs)];
+	const size_t bytes = (size_t)depth * (size_t)c->nx * c->real_size;
+	for (int f = 0; f < (with_v ? 2 : 1); f++) {
+		void *mine = c->plane[plane_index][f];
+		HIP_TRY(c, hipMemcpyPeerAsync(c->row_ptr(mine, -depth), c->device, prev->row_ptr(prev->plane[plane_index][f], prev->nyl - depth), prev->device,
+		                              bytes, c->comm));
+		HIP_TRY(c, hipMemcpyPeerAsync(c->row_ptr(mine, c->nyl), c->device, next->row_ptr(next->plane[plane_index][f], 0), next->device, bytes, c->comm));
+	}
+	return CRD_OK;
+}
+
+}  // namespace
+
+// Exchange for every context of the call: the comm streams first wait for the producers of the rows that travel, then carry
+// the transfers and record each context's halo event; the caller orders the compute streams against those events.
+int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_v)
+{
+	// comm streams wait for the producers of the edge rows
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		if (c->halo == CRD_HALO_LOCAL) {
+			// pulling from neighbours: their edge rows must be complete too
+			crd_ctx *prev = c->group[(size_t)((c->slab + c->n_slabs - 1) % c->n_slabs)];
+			crd_ctx *next = c->group[(size_t)((c->slab + 1) % c->n_slabs)];
+			HIP_TRY(c, hipStreamWaitEvent(c->comm, prev->ev_edges, 0));
+			HIP_TRY(c, hipStreamWaitEvent(c->comm, next->ev_edges, 0));
+		}
+		HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_edges, 0));
+	}
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		int rc = (c->halo == CRD_HALO_RCCL) ? exchange_rccl(c, c->planes(plane_index), depth, with_v) : exchange_local_pull(c, plane_index, depth, with_v);
+		if (rc) return rc;
+		HIP_TRY(c, hipEventRecord(c->ev_halo, c->comm));
+	}
+	return CRD_OK;
+}
+
+int prime_halo(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_v)
+{
+	for (int k = 0; k < n; k++) {
+		if (int rc = set_device(cs[k])) return rc;
+		HIP_TRY(cs[k], hipEventRecord(cs[k]->ev_edges, cs[k]->compute));
+		HIP_TRY(cs[k], hipEventRecord(cs[k]->ev_interior, cs[k]->compute));
+	}
+	return exchange_stage_input(cs, n, plane_index, depth, with_v);
+}
+
+}  // namespace crd

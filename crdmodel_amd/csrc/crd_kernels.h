@@ -1,4 +1,4 @@
-// crd_kernels.h -- launch interface between the context code (crd_context.cpp) and the HIP kernels
+// crd_kernels.h -- launch interface between the context code (crd_context.cpp, crd_steppers.cpp) and the HIP kernels
 // (crd_kernels.hip).  Plain structs; every pointer is a device pointer on the context's device.
 #pragma once
 

@@ -1,0 +1,488 @@
+// crd_steppers.cpp -- the time-stepping drivers behind the C ABI: classical RK4 with the staged or the fused kernels on one
+// slab or on the slabs of a run (deep-halo exchange cycles), and the error-controlled RK4(3) integrator.  Host code only.
+#include <algorithm>
+#include <cmath>
+
+#include "crd_ctx.h"
+
+namespace crd {
+
+namespace {
+
+struct StagePlan {
+	int in, out;
+	double c;  // stage time = t + c dt
+};
+const StagePlan kStages[4] = {{crd_ctx::Y, crd_ctx::SA, 0.0}, {crd_ctx::SA, crd_ctx::SB, 0.5}, {crd_ctx::SB, crd_ctx::SA, 0.5}, {crd_ctx::SA, crd_ctx::Y, 1.0}};
+
+StageCall make_stage_call(const crd_ctx *c, int stage, double t, double dt)
+{
+	const StagePlan &sp = kStages[stage - 1];
+	StageCall call{};
+	call.stage = stage;
+	call.dt = dt;
+	call.absorb = absorbing(c, t + sp.c * dt) ? 1 : 0;
+	call.yin = c->planes(sp.in);
+	call.y0 = c->planes(crd_ctx::Y);
+	call.acc = c->planes(crd_ctx::ACC);
+	call.yout = c->planes(sp.out);
+	return call;
+}
+
+// Single slab: four launches per step, phi wrap inside the kernel.
+int staged_step_self(crd_ctx *c, double t, double dt, hipEvent_t *k_begin, hipEvent_t *k_end)
+{
+	for (int stage = 1; stage <= 4; stage++) {
+		const StageCall call = make_stage_call(c, stage, t, dt);
+		if (stage == 2 && k_begin) HIP_TRY(c, hipEventRecord(*k_begin, c->compute));
+		HIP_TRY(c, launch_stage(c->p.precision, c->desc, call, 0, c->nyl, c->compute));
+		if (stage == 2 && k_end) HIP_TRY(c, hipEventRecord(*k_end, c->compute));
+	}
+	return CRD_OK;
+}
+
+int fused_step_self(crd_ctx *c, double t, double dt, int src, int dst, hipEvent_t *k_begin, hipEvent_t *k_end)
+{
+	const FusedCall call = make_fused_call(c, t, dt, src, dst);
+	if (k_begin) HIP_TRY(c, hipEventRecord(*k_begin, c->compute));
+	HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
+	if (k_end) HIP_TRY(c, hipEventRecord(*k_end, c->compute));
+	return CRD_OK;
+}
+
+// Several slabs (LOCAL group driven by one thread, or this rank's slab under RCCL).  Per stage:
+//   compute: [wait halo(in)] boundary rows 0 and nyl-1 -> record edges(out) -> interior rows
+//   comm:    wait edges(out) -> exchange one ghost row of out.u -> record halo(out)
+// so the exchange of stage s+1's input overlaps stage s's interior sweep.  The step's first input (Y) has its
+// halo exchanged at the end of the previous step's stage 4 (or by prime_halo before the first step).
+int staged_step_multi(crd_ctx *const *cs, int n, double t, double dt, bool timed_step)
+{
+	for (int stage = 1; stage <= 4; stage++) {
+		const StagePlan &sp = kStages[stage - 1];
+		for (int k = 0; k < n; k++) {
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			const StageCall call = make_stage_call(c, stage, t, dt);
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			HIP_TRY(c, launch_stage(c->p.precision, c->desc, call, 0, 1, c->compute));
+			HIP_TRY(c, launch_stage(c->p.precision, c->desc, call, c->nyl - 1, c->nyl, c->compute));
+			HIP_TRY(c, hipEventRecord(c->ev_edges, c->compute));
+		}
+		// start moving the edge rows of `out` while the interiors run
+		if (int rc = exchange_stage_input(cs, n, sp.out, 1, false)) return rc;
+		for (int k = 0; k < n; k++) {
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			const StageCall call = make_stage_call(c, stage, t, dt);
+			const bool timed = timed_step && stage == 2 && !c->ev_k.empty();
+			if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
+			HIP_TRY(c, launch_stage(c->p.precision, c->desc, call, 1, c->nyl - 1, c->compute));
+			if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
+		}
+	}
+	return CRD_OK;
+}
+
+// Fused stepper on several slabs: ONE exchange every kExchangeEvery steps, kGhost = 4 * kExchangeEvery ghost rows of both
+// fields.  Step q of a cycle (q = 0 right after an exchange) produces rows [-e, nyl + e) with e = 4 (kExchangeEvery-1-q):
+// the still-valid part of the ghost region is recomputed redundantly (same kernel, same inputs, so bit-identical to what
+// the owning slab computes) instead of being communicated.  Only the last step of a cycle (e = 0) is split:
+//   band:    [wait previous step] edge bands [0, B) and [nyl-B, nyl) in one launch -> record edges
+//   comm:    wait edges -> exchange kGhost rows of u and v with the ring neighbours -> record halo
+//   compute: interior [B, nyl-B) (needs neither ghost rows nor the bands)         -> record interior
+// so the exchange overlaps an interior sweep, and the first step of the next cycle waits for edges + halo.  Per step that
+// is 1.25 launches and a quarter of an RCCL group on the host, against 3 launches + 1 group for a per-step exchange.
+constexpr int kFusedBand = 32;
+static_assert(kFusedBand >= kGhost, "the edge bands must contain every row the exchange sends");
+
+// The edge-band stream exists only in contexts that step a multi-slab run with the fused stepper; it is created on first use.
+int ensure_band_stream(crd_ctx *c)
+{
+	if (c->band || !c->bands_on_own_stream) return CRD_OK;
+	if (!c->streams->band) {
+		int lo = 0, hi = 0;  // the band launch is tiny and on the critical path of the exchange: give it priority over the interior sweep
+		HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
+		HIP_TRY(c, hipStreamCreateWithPriority(&c->streams->band, hipStreamNonBlocking, hi));
+	}
+	c->band = c->streams->band;
+	return CRD_OK;
+}
+
+int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, bool timed_step)
+{
+	const int ext = kStepHalo * (kExchangeEvery - 1 - q);
+	if (q < kExchangeEvery - 1) {
+		for (int k = 0; k < n; k++) {
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			const FusedCall call = make_fused_call(c, t, dt, src, dst);
+			const bool timed = timed_step && !c->ev_k.empty();
+			if (q > 0) {
+				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
+				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
+				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
+				HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
+				continue;
+			}
+			// First step after an exchange.  Output rows [kStepHalo, nyl - kStepHalo) read owned rows only, so they are launched
+			// as soon as the bands of the previous step are in: the exchange gets this sweep as extra time to land.
+			const bool split = c->nyl >= 4 * kFusedBand;
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));
+			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kStepHalo, c->nyl - kStepHalo, 0, 0, c->compute));
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			if (c->halo == CRD_HALO_LOCAL) {
+				// LOCAL halos are PULLED by the neighbours from this context's planes: the next step that overwrites those
+				// rows (q = 1) must not start before both neighbours have finished copying them
+				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + c->n_slabs - 1) % c->n_slabs)]->ev_halo, 0));
+				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + 1) % c->n_slabs)]->ev_halo, 0));
+			}
+			// the rows that read ghost rows: [-ext, kStepHalo) and [nyl - kStepHalo, nyl + ext) in one launch
+			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, kStepHalo, c->nyl - kStepHalo, c->nyl + ext, c->compute));
+			else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
+			HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
+		}
+		return CRD_OK;
+	}
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		const FusedCall call = make_fused_call(c, t, dt, src, dst);
+		const bool split = c->nyl >= 4 * kFusedBand;
+		if (int rc = ensure_band_stream(c)) return rc;
+		hipStream_t bs = c->bands_on_own_stream ? c->band : c->compute;
+		if (kExchangeEvery == 1) {  // per-step exchange: this step's inputs were produced by the previous split step
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));
+			HIP_TRY(c, hipStreamWaitEvent(bs, c->ev_halo, 0));
+		}
+		HIP_TRY(c, hipStreamWaitEvent(bs, c->ev_interior, 0));  // previous step done: its output is read, its input plane is overwritten
+		if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, kFusedBand, c->nyl - kFusedBand, c->nyl, bs));
+		else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, bs));
+		HIP_TRY(c, hipEventRecord(c->ev_edges, bs));
+	}
+	if (int rc = exchange_stage_input(cs, n, dst, kGhost, true)) return rc;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		if (c->nyl >= 4 * kFusedBand) {
+			const FusedCall call = make_fused_call(c, t, dt, src, dst);
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kFusedBand, c->nyl - kFusedBand, 0, 0, c->compute));
+		}
+		HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
+	}
+	return CRD_OK;
+}
+
+constexpr int kMaxTimedLaunches = 64;
+// Step of an exchange cycle whose single full-slab launch is the one timed in a multi-slab fused run (step 0 is split in two).
+constexpr int kTimedCycleStep = (kExchangeEvery > 2) ? 1 : 0;
+
+int ensure_timing_events(crd_ctx *c)
+{
+	while ((int)c->ev_k.size() < 2 * kMaxTimedLaunches) {
+		hipEvent_t e;
+		HIP_TRY(c, hipEventCreate(&e));
+		c->ev_k.push_back(e);
+	}
+	return CRD_OK;
+}
+
+}  // namespace
+
+FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int dst)
+{
+	FusedCall call{};
+	call.dt = dt;
+	const double cs[4] = {0.0, 0.5, 0.5, 1.0};
+	for (int k = 0; k < 4; k++) call.absorb[k] = absorbing(c, t + cs[k] * dt) ? 1 : 0;
+	call.y0 = c->planes(src);
+	call.yout = c->planes(dst);
+	return call;
+}
+
+// The stepping loop shared by crd_step_rk4 / crd_step_rk4_timed / the group call.
+int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, int *timed_launches)
+{
+	crd_ctx *lead = cs[0];
+	if (nsteps < 0 || !(dt > 0.0) || !std::isfinite(t0)) return fail(lead, CRD_EINVAL, "bad t0 / dt / nsteps");
+	const int stepper = resolve_stepper(lead);
+	if (stepper < 0) return fail(lead, CRD_EINVAL, "fused stepper not available for this configuration");
+	for (int k = 0; k < n; k++)
+		if (resolve_stepper(cs[k]) != stepper) return fail(lead, CRD_EINVAL, "contexts of one run disagree on the stepper");
+	int timed = 0;
+	const bool single = (lead->halo == CRD_HALO_SELF);
+	if (single) {
+		crd_ctx *c = lead;
+		if (int rc = set_device(c)) return rc;
+		int cur = crd_ctx::Y;
+		for (int64_t s = 0; s < nsteps; s++) {
+			const double t = t0 + (double)s * dt;
+			hipEvent_t *kb = nullptr, *ke = nullptr;
+			if (timed_launches && timed < kMaxTimedLaunches && (s * kMaxTimedLaunches / std::max<int64_t>(nsteps, 1)) >= timed) {
+				kb = &c->ev_k[(size_t)(2 * timed)];
+				ke = &c->ev_k[(size_t)(2 * timed + 1)];
+				timed++;
+			}
+			int rc;
+			if (stepper == CRD_STEPPER_STAGED) {
+				rc = staged_step_self(c, t, dt, kb, ke);
+			} else {
+				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
+				rc = fused_step_self(c, t, dt, cur, dst, kb, ke);
+				cur = dst;
+			}
+			if (rc) return rc;
+		}
+		if (cur != crd_ctx::Y) {  // odd number of fused steps: the result sits in SA; swap the plane pointers
+			std::swap(c->plane[crd_ctx::Y][0], c->plane[crd_ctx::SA][0]);
+			std::swap(c->plane[crd_ctx::Y][1], c->plane[crd_ctx::SA][1]);
+		}
+	} else {
+		const bool fused = (stepper == CRD_STEPPER_FUSED);
+		if (nsteps > 0)
+			if (int rc = prime_halo(cs, n, crd_ctx::Y, fused ? kGhost : 1, fused)) return rc;
+		int cur = crd_ctx::Y;
+		for (int64_t s = 0; s < nsteps; s++) {
+			// time one launch of the dominant kernel mid-run (fused: the first one-launch step of a cycle)
+			const bool timed_step = timed_launches && !timed &&
+			                        (fused ? (s % kExchangeEvery == kTimedCycleStep && (s >= nsteps / 2 || s + kExchangeEvery >= nsteps)) : s >= nsteps / 2);
+			const double t = t0 + (double)s * dt;
+			if (fused) {
+				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
+				if (int rc = fused_step_multi(cs, n, t, dt, cur, dst, (int)(s % kExchangeEvery), timed_step)) return rc;
+				cur = dst;
+			} else if (int rc = staged_step_multi(cs, n, t, dt, timed_step)) {
+				return rc;
+			}
+			if (timed_step) timed = 1;
+		}
+		if (cur != crd_ctx::Y)
+			for (int k = 0; k < n; k++) {
+				std::swap(cs[k]->plane[crd_ctx::Y][0], cs[k]->plane[crd_ctx::SA][0]);
+				std::swap(cs[k]->plane[crd_ctx::Y][1], cs[k]->plane[crd_ctx::SA][1]);
+			}
+		// leave the compute stream of every context ordered behind its last band launch and exchange
+		for (int k = 0; k < n; k++) {
+			if (int rc = set_device(cs[k])) return rc;
+			HIP_TRY(cs[k], hipStreamWaitEvent(cs[k]->compute, cs[k]->ev_edges, 0));
+			HIP_TRY(cs[k], hipStreamWaitEvent(cs[k]->compute, cs[k]->ev_halo, 0));
+		}
+	}
+	if (timed_launches) *timed_launches = timed;
+	return CRD_OK;
+}
+
+}  // namespace crd
+
+using namespace crd;
+
+extern "C" {
+
+int crd_set_stepper(crd_ctx *c, int stepper)
+{
+	if (!c) return CRD_EINVAL;
+	if (stepper != CRD_STEPPER_AUTO && stepper != CRD_STEPPER_STAGED && stepper != CRD_STEPPER_FUSED) return fail(c, CRD_EINVAL, "unknown stepper");
+	if (stepper == CRD_STEPPER_FUSED && !fused_step_supported(c->p.precision, c->desc)) return fail(c, CRD_EINVAL, "fused stepper not available for this configuration");
+	c->stepper = stepper;
+	return CRD_OK;
+}
+
+int crd_step_rk4(crd_ctx *c, double t0, double dt, int64_t nsteps)
+{
+	if (!c) return CRD_EINVAL;
+	if (c->halo < 0) return fail(c, CRD_ESTATE, "multi-slab context is not wired (crd_comm_attach_local / crd_comm_init_rccl)");
+	if (c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "LOCAL groups step through crd_group_step_rk4");
+	crd_ctx *one[1] = {c};
+	return run_steps(one, 1, t0, dt, nsteps, nullptr);
+}
+
+int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps)
+{
+	if (int rc = check_group(ctxs, n)) return rc;
+	if (n > 1)
+		for (int k = 0; k < n; k++)
+			if (ctxs[k]->halo != CRD_HALO_LOCAL) return fail(ctxs[0], CRD_ESTATE, "group is not attached");
+	return run_steps(ctxs, n, t0, dt, nsteps, nullptr);
+}
+
+int crd_adaptive_defaults(crd_adaptive_options *o)
+{
+	if (!o) return CRD_EINVAL;
+	o->rtol = 1.e-5;   // src/FHNmodel_torus.cpp:197
+	o->atol = 1.e-10;  // :198
+	o->h0 = 0.0;
+	o->safety = 0.96;
+	o->bias = 1.5;
+	o->growth = 20.0;
+	o->shrink = 0.1;
+	o->max_steps = 200000;  // :372
+	return CRD_OK;
+}
+
+// Error-controlled integration of all slabs of a run (n = 1: a single-slab or RCCL context; n > 1: a LOCAL group).
+static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double tout, const crd_adaptive_options *opt_in, crd_adaptive_stats *stats)
+{
+	crd_ctx *lead = cs[0];
+	crd_adaptive_options o;
+	crd_adaptive_defaults(&o);
+	if (opt_in) o = *opt_in;
+	if (!(o.rtol >= 0.0) || !(o.atol >= 0.0) || !(o.rtol + o.atol > 0.0) || !(o.safety > 0.0) || !(o.bias > 0.0) || !(o.growth >= 1.0) ||
+	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0)
+		return fail(lead, CRD_EINVAL, "bad adaptive options / time interval");
+	const bool multi = lead->halo != CRD_HALO_SELF;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (!fused_step_supported(c->p.precision, c->desc)) return fail(lead, CRD_EINVAL, "slab too small for the fused step kernel");
+		if (int rc = set_device(c)) return rc;
+		if (!c->err_partials) {
+			c->err_capacity = fused_max_items(c->desc);
+			HIP_TRY(c, hipMalloc((void **)&c->err_partials, sizeof(double) * (size_t)c->err_capacity));
+		}
+	}
+	crd_adaptive_stats st{};
+	double t = t0;
+	double h = o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&lead->p);
+	const double n_components = 2.0 * (double)lead->g.nx * (double)lead->g.ny;  // WRMS norm over the whole grid
+	constexpr int kEmbedHalo = kStepHalo + 1;                                     // the fifth stage reads one more row
+	int cur = crd_ctx::Y;
+	bool after_reject = false;
+	int rc = CRD_OK;
+	while (t < tout) {
+		if (st.accepted + st.rejected >= o.max_steps) {
+			rc = fail(lead, CRD_ESTATE, "adaptive integration: max_steps attempts taken before reaching tout");
+			break;
+		}
+		double hh = h;
+		bool clipped = false;
+		if (t + hh >= tout || tout - (t + hh) < 1e-12 * std::fabs(tout)) {  // land on tout exactly; absorb a sliver of a last step
+			hh = tout - t;
+			clipped = true;
+		}
+		if (!(hh > 1e-14 * std::fmax(std::fabs(t), 1e-300)) && !(t == 0.0 && hh > 0.0)) {
+			rc = fail(lead, CRD_ESTATE, "adaptive integration: step size underflow");
+			break;
+		}
+		const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
+		if (multi)  // every attempt starts from freshly exchanged ghost rows of the current state (no overlap: the host waits for the norm anyway)
+			if ((rc = prime_halo(cs, n, cur, kEmbedHalo, true))) break;
+		double sum = 0.0;
+		for (int k = 0; k < n && rc == CRD_OK; k++) {
+			crd_ctx *c = cs[k];
+			if ((rc = set_device(c))) break;
+			FusedCall call = make_fused_call(c, t, hh, cur, dst);
+			call.embed = 1;
+			call.rtol = o.rtol;
+			call.atol = o.atol;
+			call.err_partials = c->err_partials;
+			call.err_capacity = c->err_capacity;
+			call.err_sum = c->scalar_dev;
+			if (multi) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
+			if (c->halo == CRD_HALO_RCCL)  // every rank gets the same bits, hence takes the same decision
+				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev, c->scalar_dev, 1, ncclDouble, ncclSum, c->nccl, c->compute));
+		}
+		for (int k = 0; k < n && rc == CRD_OK; k++) {  // LOCAL groups: add the slabs' sums in slab order
+			crd_ctx *c = cs[k];
+			if ((rc = set_device(c))) break;
+			double part = 0.0;
+			HIP_TRY(c, hipMemcpyAsync(&part, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
+			HIP_TRY(c, hipStreamSynchronize(c->compute));
+			sum += part;
+		}
+		if (rc != CRD_OK) break;
+		const double err = o.bias * std::sqrt(sum / n_components);
+		st.err_last = err;
+		double eta;
+		if (!(err == err) || std::isinf(err)) eta = o.shrink;  // NaN / inf: the step blew up
+		else if (err <= 0.0) eta = o.growth;
+		else eta = std::fmin(o.growth, std::fmax(o.shrink, o.safety * std::pow(err, -0.25)));
+		if (err <= 1.0) {
+			t = clipped ? tout : t + hh;
+			cur = dst;
+			st.accepted++;
+			if (after_reject) eta = std::fmin(eta, 1.0);  // no growth right after a rejection
+			after_reject = false;
+			if (!clipped || st.accepted == 1) {
+				st.h_last = hh;
+				st.h_min = (st.h_min == 0.0) ? hh : std::fmin(st.h_min, hh);
+				st.h_max = std::fmax(st.h_max, hh);
+			}
+			if (!clipped) h = hh * eta;
+			else h = std::fmax(h, hh * eta);  // a step shortened to hit tout says nothing against the step it replaced
+		} else {
+			st.rejected++;
+			after_reject = true;
+			h = hh * std::fmin(eta, 0.9);
+		}
+	}
+	if (cur != crd_ctx::Y)
+		for (int k = 0; k < n; k++) {
+			std::swap(cs[k]->plane[crd_ctx::Y][0], cs[k]->plane[crd_ctx::SA][0]);
+			std::swap(cs[k]->plane[crd_ctx::Y][1], cs[k]->plane[crd_ctx::SA][1]);
+		}
+	st.t = t;
+	st.h_next = h;
+	if (stats) *stats = st;
+	return rc;
+}
+
+int crd_integrate_adaptive(crd_ctx *c, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats)
+{
+	if (!c) return CRD_EINVAL;
+	if (c->halo < 0) return fail(c, CRD_ESTATE, "multi-slab context is not wired (crd_comm_attach_local / crd_comm_init_rccl)");
+	if (c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "LOCAL groups integrate through crd_group_integrate_adaptive");
+	crd_ctx *one[1] = {c};
+	return integrate_adaptive_impl(one, 1, t0, tout, opt, stats);
+}
+
+int crd_group_integrate_adaptive(crd_ctx *const *ctxs, int n, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats)
+{
+	if (int rc = check_group(ctxs, n)) return rc;
+	if (n > 1)
+		for (int k = 0; k < n; k++)
+			if (ctxs[k]->halo != CRD_HALO_LOCAL) return fail(ctxs[0], CRD_ESTATE, "group is not attached");
+	return integrate_adaptive_impl(ctxs, n, t0, tout, opt, stats);
+}
+
+int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double *ms_total, double *kernel_ms, int *launches_per_step)
+{
+	if (!c) return CRD_EINVAL;
+	if (c->halo < 0 || c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "timed stepping needs a single-slab or RCCL context");
+	if (int rc = set_device(c)) return rc;
+	if (int rc = ensure_timing_events(c)) return rc;
+	crd_ctx *one[1] = {c};
+	int timed = 0;
+	HIP_TRY(c, hipEventRecord(c->ev_t0, c->compute));
+	if (int rc = run_steps(one, 1, t0, dt, nsteps, &timed)) return rc;
+	HIP_TRY(c, hipEventRecord(c->ev_t1, c->compute));
+	HIP_TRY(c, hipEventSynchronize(c->ev_t1));
+	float ms = 0.f;
+	HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+	if (ms_total) *ms_total = ms;
+	double sum = 0.0;
+	for (int k = 0; k < timed; k++) {
+		float m = 0.f;
+		HIP_TRY(c, hipEventElapsedTime(&m, c->ev_k[(size_t)(2 * k)], c->ev_k[(size_t)(2 * k + 1)]));
+		sum += m;
+	}
+	if (kernel_ms) *kernel_ms = timed ? sum / timed : 0.0;
+	if (launches_per_step) *launches_per_step = (resolve_stepper(c) == CRD_STEPPER_FUSED) ? 1 : 2;
+	return CRD_OK;
+}
+
+int crd_dominant_kernel_rows(const crd_ctx *c, int64_t *rows)
+{
+	if (!c || !rows) return CRD_EINVAL;
+	const int stepper = resolve_stepper(c);
+	if (c->halo == CRD_HALO_SELF) *rows = c->nyl;
+	else if (stepper == CRD_STEPPER_FUSED) *rows = c->nyl + 2 * kStepHalo * (kExchangeEvery - 1 - kTimedCycleStep);  // the timed step of an exchange cycle
+	else *rows = c->nyl - 2;
+	return CRD_OK;
+}
+
+const char *crd_dominant_kernel_name(const crd_ctx *c)
+{
+	if (!c) return "";
+	return resolve_stepper(c) == CRD_STEPPER_FUSED ? fused_kernel_name(c->p.precision, c->p.model) : stage_kernel_name(c->p.precision, c->p.model);
+}
+
+}  // extern "C"
