@@ -30,7 +30,8 @@ using namespace dev;
 constexpr int kApron = 4;                    // RK4 stages = halo depth
 constexpr int kLanes = 64;
 constexpr int kValid = kLanes - 2 * kApron;  // 56 output columns per wavefront
-constexpr int kWavesPerBlock = 4;
+constexpr int kWavesPerBlock = 4;     // default; the launch may use 1 .. kMaxWavesPerBlock (tuning knob)
+constexpr int kMaxWavesPerBlock = 8;
 constexpr int kPrefetch = 4;                 // rows in flight per wavefront; equals the unroll factor so slots stay static
 
 // Value held by lane-1 / lane+1 of this wavefront (the edge lane gets 0: it is apron garbage by design).  `old` = 0 with
@@ -88,6 +89,9 @@ struct FusedArgs {
 	int nchunks1;             // chunks of the first range
 	int chunk;                // rows per work item
 	int nstrips, nitems, nblocks, remap;
+	int nchunks;              // chunks of both ranges
+	int sw;                   // wavefronts per block = adjacent strips a block covers
+	int lockstep;             // the block's wavefronts march in step (one barrier per pipeline iteration)
 	double *err_partials;     // EMBED: one weighted square sum per work item
 	Real rtol, atol;          // EMBED: error weights 1 / (rtol |y_n| + atol)
 };
@@ -102,7 +106,7 @@ struct FusedArgs {
 // sqrt(sum / N)).  The propagated solution is classical RK4 either way.  The pipeline is then five rows / columns deep
 // (apron 5, 54 valid lanes) and uses 8 register slots per array, the loop being unrolled 8 times.
 template <typename Real, int MODEL, bool ABSORB, bool EMBED>
-__global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
+__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
 	constexpr int APRON = EMBED ? kApron + 1 : kApron;
 	constexpr int VALID = kLanes - 2 * APRON;
@@ -111,10 +115,15 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
 	// per-row table reads, the boundary-row tests) in scalar registers.
 	// Optional remap: blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of items.
-	const int item = __builtin_amdgcn_readfirstlane((a.remap ? xcd_remap((int)blockIdx.x, a.nblocks) : (int)blockIdx.x) * kWavesPerBlock + (int)(threadIdx.x >> 6));
-	if (item >= a.nitems) return;
-	// consecutive items walk theta first: the four wavefronts of a block read adjacent, overlapping strips
-	const int strip = item % a.nstrips, chunk = item / a.nstrips;
+	// A block's wavefronts take adjacent strips of ONE chunk, blocks walk theta first.  The wavefronts of a block therefore
+	// run the same trip counts, and in lockstep (one barrier per pipeline iteration) their row reads reach the memory system
+	// together as one contiguous, overlapping run of a.sw x 448 B per row instead of drifting apart.
+	const int blk = a.remap ? xcd_remap((int)blockIdx.x, a.nblocks) : (int)blockIdx.x;
+	const int nsb = (a.nstrips + a.sw - 1) / a.sw;
+	const int strip = __builtin_amdgcn_readfirstlane((blk % nsb) * a.sw + (int)(threadIdx.x >> 6));
+	const int chunk = __builtin_amdgcn_readfirstlane(blk / nsb);
+	if (strip >= a.nstrips || chunk >= a.nchunks) return;  // (a barrier waits for the surviving wavefronts of the workgroup only)
+	const int item = chunk * a.nstrips + strip;
 	const int nx = s.nx;
 
 	int x = strip * VALID - APRON + lane;  // this lane's column, wrapped periodically (nx may be smaller than 64)
@@ -181,6 +190,7 @@ __global__ void __launch_bounds__(kLanes *kWavesPerBlock) crd_rk4_fused_step_ker
 	auto iteration = [&](int m, auto kk, auto guarded) {
 		constexpr int K = decltype(kk)::value;
 		constexpr bool GUARDED = decltype(guarded)::value;
+		if (a.lockstep) __builtin_amdgcn_s_barrier();  // uniform over the block: its wavefronts share the chunk, hence niter
 		// slots of rows p, p-1, ... p-6 (with M = 4, row p-4 shares its slot with row p)
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M;
 		constexpr int S5 = (K + 2 * M - 5) % M, S6 = (K + 2 * M - 6) % M;
@@ -314,7 +324,8 @@ __global__ void __launch_bounds__(256) crd_sum_partials_kernel(const double *__r
 // speeds cost about half a round at the end whatever the count, and short chunks keep the rows two phi-neighbouring items
 // share in L2.  Measured on 8192^2 fp64 (147 strips, 4096 slots; 200-step medians, one process, tools/tune_fused.py):
 // chunk 32 0.434 ms, 24 0.451, 50 0.463, 60 0.477, 75 0.494, 128 0.51, 1024 0.62 -- many short items win.  So: 32 rows,
-// halved while the launch would not fill every slot twice.
+// halved while the launch would not fill every slot once (an 8192 x 1024 slab, one rank's share of 8 GPUs, sweeps in
+// 58.4 us with 32-row chunks and 60.5 with 16; the edge-band launches of a multi-slab step end up with 8-row chunks).
 template <typename Real, int MODEL>
 int fused_chunk_rows(int nstrips, int rows)
 {
@@ -330,7 +341,7 @@ int fused_chunk_rows(int nstrips, int rows)
 		slots = cus * blocks_per_cu * kWavesPerBlock;
 	}
 	int chunk = 32;
-	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < 2L * slots) chunk /= 2;
+	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
 	if (const char *e = std::getenv("CRD_FUSED_CHUNK")) {  // tuning knob
 		const int v = std::atoi(e);
 		if (v >= 1) chunk = v;
@@ -369,15 +380,27 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.row_end2 = row_end2;
 	a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2);
 	a.nchunks1 = (rows + a.chunk - 1) / a.chunk;
-	a.nitems = a.nstrips * (a.nchunks1 + (rows2 + a.chunk - 1) / a.chunk);
-	const int nblocks = (a.nitems + kWavesPerBlock - 1) / kWavesPerBlock;
+	a.nchunks = a.nchunks1 + (rows2 + a.chunk - 1) / a.chunk;
+	a.nitems = a.nstrips * a.nchunks;
+	// Four adjacent strips per block marching in lockstep: 0.417 ms on 8192^2 fp64 against 0.441 without the barriers and
+	// 0.4205 with one barrier per four iterations (tools/tune_fused.py, interleaved in one process; fp32 0.219 vs 0.232,
+	// Goldbeter -- instruction-bound -- unchanged); 2 or 8 strips per block lose half of the gain, 3 / 5 / 6 more.
+	int sw = kWavesPerBlock, lockstep = 1;
+	if (const char *e = std::getenv("CRD_FUSED_STRIPS")) {  // tuning knobs
+		const int v = std::atoi(e);
+		if (v >= 1 && v <= kMaxWavesPerBlock) sw = v;
+	}
+	if (const char *e = std::getenv("CRD_FUSED_LOCKSTEP")) lockstep = std::atoi(e) != 0;
+	a.sw = sw;
+	a.lockstep = lockstep;
+	const int nblocks = ((a.nstrips + sw - 1) / sw) * a.nchunks;
 	a.nblocks = nblocks;
 	a.remap = std::getenv("CRD_FUSED_REMAP") ? 1 : 0;  // tuning knob: XCD-contiguous item runs (helps long chunks, hurts 32-row ones)
 	a.err_partials = c.err_partials;
 	a.rtol = (Real)c.rtol;
 	a.atol = (Real)c.atol;
 	const bool absorb = c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3];
-	const dim3 block(kLanes * kWavesPerBlock);
+	const dim3 block(kLanes * sw);
 	if (c.embed) {
 		if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
 		if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, true, true><<<nblocks, block, 0, st>>>(s, a);
