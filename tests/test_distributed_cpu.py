@@ -60,8 +60,11 @@ def _worker(rank, world, port, result_dir):
         rng = np.random.default_rng(5)  # same field on every rank
         y_global = rng.standard_normal((g.ny, nx, 2))
 
-        # --- one halo exchange, depth 1 and depth 4: ghosts must be the periodic neighbour rows ---------------------
-        for depth in (1, 4):
+        # --- one halo exchange, depth 1, 4 and 16 (staged stepper; one fused step; the fused stepper's four-step exchange):
+        #     ghosts must be the periodic neighbour rows --------------------------------------------------------------
+        for depth in (1, 4, 16):
+            if depth > nyl:
+                continue
             plane = np.full((nyl + 2 * depth, nx), np.nan)
             plane[depth:depth + nyl] = y_global[js:je + 1, :, 0]
             _exchange(dist, plane, nyl, depth, rank, world, crd)
