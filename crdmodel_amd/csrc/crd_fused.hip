@@ -319,6 +319,14 @@ __global__ void __launch_bounds__(256) crd_sum_partials_kernel(const double *__r
 	if (threadIdx.x == 0) *out = part[0];
 }
 
+// Tuning knobs (tools/tune_fused.py, tools/ring_ab.py flip them between launches of one process).  They are honoured only
+// when CRD_TUNING is set in the environment at the first launch; a production process never reads them.
+const char *tuning_knob(const char *name)
+{
+	static const bool enabled = std::getenv("CRD_TUNING") != nullptr;
+	return enabled ? std::getenv(name) : nullptr;
+}
+
 // Rows per work item.  Every item pays 8 apron rows, which argues for long chunks; but the wavefronts of a launch run in
 // "rounds" of (resident wavefront slots) items, a partly filled last round idles most of the chip, unequal wavefront
 // speeds cost about half a round at the end whatever the count, and short chunks keep the rows two phi-neighbouring items
@@ -342,7 +350,7 @@ int fused_chunk_rows(int nstrips, int rows)
 	}
 	int chunk = 32;
 	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
-	if (const char *e = std::getenv("CRD_FUSED_CHUNK")) {  // tuning knob
+	if (const char *e = tuning_knob("CRD_FUSED_CHUNK")) {  // tuning knob
 		const int v = std::atoi(e);
 		if (v >= 1) chunk = v;
 	}
@@ -386,16 +394,16 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	// 0.4205 with one barrier per four iterations (tools/tune_fused.py, interleaved in one process; fp32 0.219 vs 0.232,
 	// Goldbeter -- instruction-bound -- unchanged); 2 or 8 strips per block lose half of the gain, 3 / 5 / 6 more.
 	int sw = kWavesPerBlock, lockstep = 1;
-	if (const char *e = std::getenv("CRD_FUSED_STRIPS")) {  // tuning knobs
+	if (const char *e = tuning_knob("CRD_FUSED_STRIPS")) {  // tuning knobs
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= kMaxWavesPerBlock) sw = v;
 	}
-	if (const char *e = std::getenv("CRD_FUSED_LOCKSTEP")) lockstep = std::atoi(e) != 0;
+	if (const char *e = tuning_knob("CRD_FUSED_LOCKSTEP")) lockstep = std::atoi(e) != 0;
 	a.sw = sw;
 	a.lockstep = lockstep;
 	const int nblocks = ((a.nstrips + sw - 1) / sw) * a.nchunks;
 	a.nblocks = nblocks;
-	a.remap = std::getenv("CRD_FUSED_REMAP") ? 1 : 0;  // tuning knob: XCD-contiguous item runs (helps long chunks, hurts 32-row ones)
+	a.remap = tuning_knob("CRD_FUSED_REMAP") ? 1 : 0;  // tuning knob: XCD-contiguous item runs (helps long chunks, hurts 32-row ones)
 	a.err_partials = c.err_partials;
 	a.rtol = (Real)c.rtol;
 	a.atol = (Real)c.atol;

@@ -1,6 +1,8 @@
 // crd_halo.cpp -- the RCCL binding and the halo transports of multi-slab runs.  Host code only.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "crd_ctx.h"
 
 namespace crd {
@@ -9,6 +11,8 @@ RcclApi g_rccl;
 
 bool RcclApi::load()
 {
+	static std::mutex once;  // contexts are per-thread objects, the binding is per-process
+	std::lock_guard<std::mutex> lock(once);
 	if (handle) return true;
 	if (!error.empty()) return false;
 	for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {

@@ -6,6 +6,7 @@ import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["CRD_TUNING"] = "1"  # the library honours the launch-time knobs only under this switch
 import crdmodel_amd as crd  # noqa: E402
 
 n = int(os.environ.get("TUNE_SIZE", "8192"))
