@@ -86,12 +86,15 @@ int staged_step_multi(crd_ctx *const *cs, int n, double t, double dt, bool timed
 // Fused stepper on several slabs: ONE exchange every kExchangeEvery steps, kGhost = 4 * kExchangeEvery ghost rows of both
 // fields.  Step q of a cycle (q = 0 right after an exchange) produces rows [-e, nyl + e) with e = 4 (kExchangeEvery-1-q):
 // the still-valid part of the ghost region is recomputed redundantly (same kernel, same inputs, so bit-identical to what
-// the owning slab computes) instead of being communicated.  Only the last step of a cycle (e = 0) is split:
+// the owning slab computes) instead of being communicated.  The last step of a cycle (e = 0) is split
 //   band:    [wait previous step] edge bands [0, B) and [nyl-B, nyl) in one launch -> record edges
 //   comm:    wait edges -> exchange kGhost rows of u and v with the ring neighbours -> record halo
 //   compute: interior [B, nyl-B) (needs neither ghost rows nor the bands)         -> record interior
-// so the exchange overlaps an interior sweep, and the first step of the next cycle waits for edges + halo.  Per step that
-// is 1.25 launches and a quarter of an RCCL group on the host, against 3 launches + 1 group for a per-step exchange.
+// and so is the first step of the next cycle
+//   compute: rows [4, nyl-4), which read owned rows only, straight after the interior sweep
+//   compute: [wait halo] rows [-e, 4) and [nyl-4, nyl+e), the ones that read ghost rows, in one small launch
+// so the exchange has two sweeps to hide under.  Per step that is 1.5 launches and a quarter of an RCCL group on the host,
+// against 3 launches + 1 group for a per-step exchange.
 constexpr int kFusedBand = 32;
 static_assert(kFusedBand >= kGhost, "the edge bands must contain every row the exchange sends");
 
