@@ -17,7 +17,7 @@ bool validate_params(const crd_params &p, std::string *why)
 	if (p.model != CRD_MODEL_FHN && p.model != CRD_MODEL_GOLDBETER) return fail("model must be CRD_MODEL_FHN or CRD_MODEL_GOLDBETER");
 	if (p.surface != CRD_SURFACE_TORUS && p.surface != CRD_SURFACE_FLAT) return fail("surface must be CRD_SURFACE_TORUS or CRD_SURFACE_FLAT");
 	if (p.precision != CRD_PRECISION_F64 && p.precision != CRD_PRECISION_F32) return fail("precision must be CRD_PRECISION_F64 or CRD_PRECISION_F32");
-	if (p.nx < 2 || p.nx > INT32_MAX) return fail("nx (thetaMesh / xMesh) must be in [2, 2^31)");
+	if (p.nx < 2 || p.nx > (1 << 24)) return fail("nx (thetaMesh / xMesh) must be in [2, 2^24] (the kernels index columns with 32-bit integers)");
 	if (p.ny < 0 || p.ny > INT32_MAX) return fail("ny (phiMesh) must be in [0, 2^31)");
 	if (!(p.surface_length > 0.0) || !(p.surface_width > 0.0)) return fail("surfaceLength and surfaceWidth must be positive");
 	if (!std::isfinite(p.diffusion) || !std::isfinite(p.beta) || !std::isfinite(p.beta_min) || !std::isfinite(p.beta_max) ||
