@@ -57,7 +57,7 @@ class AdaptiveOptions(C.Structure):
     """crd_adaptive_options"""
 
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("h0", C.c_double), ("safety", C.c_double), ("bias", C.c_double),
-                ("growth", C.c_double), ("shrink", C.c_double), ("max_steps", C.c_int64)]
+                ("growth", C.c_double), ("shrink", C.c_double), ("max_steps", C.c_int64), ("h_max", C.c_double)]
 
 
 class AdaptiveStats(C.Structure):

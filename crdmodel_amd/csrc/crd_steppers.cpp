@@ -318,6 +318,7 @@ int crd_adaptive_defaults(crd_adaptive_options *o)
 	o->growth = 20.0;
 	o->shrink = 0.1;
 	o->max_steps = 200000;  // :372
+	o->h_max = 0.0;         // automatic: the diffusion-stability bound
 	return CRD_OK;
 }
 
@@ -329,7 +330,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	crd_adaptive_defaults(&o);
 	if (opt_in) o = *opt_in;
 	if (!(o.rtol >= 0.0) || !(o.atol >= 0.0) || !(o.rtol + o.atol > 0.0) || !(o.safety > 0.0) || !(o.bias > 0.0) || !(o.growth >= 1.0) ||
-	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0)
+	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || std::isnan(o.h_max) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0)
 		return fail(lead, CRD_EINVAL, "bad adaptive options / time interval");
 	const bool multi = lead->halo != CRD_HALO_SELF;
 	for (int k = 0; k < n; k++) {
@@ -343,7 +344,8 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	}
 	crd_adaptive_stats st{};
 	double t = t0;
-	double h = o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&lead->p);
+	const double h_cap = o.h_max > 0.0 ? o.h_max : (o.h_max == 0.0 ? crd_stable_dt(&lead->p) : INFINITY);
+	double h = std::fmin(o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&lead->p), h_cap);
 	const double n_components = 2.0 * (double)lead->g.nx * (double)lead->g.ny;  // WRMS norm over the whole grid
 	constexpr int kEmbedHalo = kStepHalo + 1;                                     // the fifth stage reads one more row
 	int cur = crd_ctx::Y;
@@ -411,6 +413,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			}
 			if (!clipped) h = hh * eta;
 			else h = std::fmax(h, hh * eta);  // a step shortened to hit tout says nothing against the step it replaced
+			h = std::fmin(h, h_cap);
 		} else {
 			st.rejected++;
 			after_reject = true;

@@ -216,7 +216,8 @@ int crd_synchronize(crd_ctx *ctx);
  * Not ARKode's step sequence: its method table and controller are not in the reference tree.  The last step
  * is shortened to land on tout (ARKode overshoots and interpolates).  Multi-slab runs exchange five ghost rows before
  * every attempt and reduce the norm over the ring (ncclAllReduce; LOCAL groups add the slabs' sums on the host in slab
- * order), so every rank takes the same decisions.  h0 = 0 starts from the diffusion-stability step. */
+ * order), so every rank takes the same decisions.  h0 = 0 starts from the diffusion-stability step; by default steps are
+ * also capped at that bound (h_max = 0), which removes the reject / regrow cycle of a stability-limited explicit method. */
 typedef struct crd_adaptive_options {
 	double rtol, atol;      /* 1e-5, 1e-10 in the reference (src/FHNmodel_torus.cpp:197-198) */
 	double h0;              /* first step; 0 = automatic */
@@ -225,6 +226,9 @@ typedef struct crd_adaptive_options {
 	double growth;          /* 20: largest h_new / h */
 	double shrink;          /* 0.1: smallest h_new / h */
 	int64_t max_steps;      /* 200000 attempts (ARKodeSetMaxNumSteps, :372) */
+	double h_max;           /* largest step: > 0 explicit cap (ARKodeSetMaxStep); 0 = the classical-RK4 stability bound of the
+	                         * diffusion operator, crd_stable_dt (what ARKodeSetStabilityFn is for: beyond it the error test
+	                         * only finds out by failing); < 0 = no cap, error control alone (ARKode's default) */
 } crd_adaptive_options;
 typedef struct crd_adaptive_stats {
 	int64_t accepted, rejected;

@@ -177,13 +177,15 @@ def rk4(p, y, t0, dt, nsteps, nthreads=1):
     return out
 
 
-def integrate_adaptive(p, y, t0, tout, h0, rtol=1e-5, atol=1e-10, safety=0.96, bias=1.5, growth=20.0, shrink=0.1, max_steps=200000, nthreads=1):
+def integrate_adaptive(p, y, t0, tout, h0, rtol=1e-5, atol=1e-10, safety=0.96, bias=1.5, growth=20.0, shrink=0.1, max_steps=200000, nthreads=1,
+                       h_max=float("inf")):
     """Error-controlled RK4(3) restated on the CPU for the tests: the step-size logic of libcrd's crd_integrate_adaptive
     around the oracle's f().  Classical RK4 propagates; k5 = f(t+h, y_new) gives the third-order embedded solution
     y + h (k1/6 + k2/3 + k3/3 + k5/6), i.e. the error estimate h (k4 - k5)/6; WRMS norm with weights 1/(rtol |y_n| + atol)
-    (the tolerances of /root/reference/src/FHNmodel_torus.cpp:197-198,365).  Returns (y(tout), stats)."""
+    (the tolerances of /root/reference/src/FHNmodel_torus.cpp:197-198,365).  Steps never exceed h_max (libcrd's default cap is
+    its crd_stable_dt; pass that value to follow it).  Returns (y(tout), stats)."""
     y = np.array(y, dtype=np.float64, order="C", copy=True)
-    t, h = float(t0), float(h0)
+    t, h = float(t0), min(float(h0), h_max)
     st = dict(accepted=0, rejected=0, h_last=0.0, h_min=0.0, h_max=0.0, err_last=0.0, steps=[])
     after_reject = False
     n = y.size
@@ -220,7 +222,7 @@ def integrate_adaptive(p, y, t0, tout, h0, rtol=1e-5, atol=1e-10, safety=0.96, b
                 st["h_last"] = hh
                 st["h_min"] = hh if st["h_min"] == 0.0 else min(st["h_min"], hh)
                 st["h_max"] = max(st["h_max"], hh)
-            h = hh * eta if not clipped else max(h, hh * eta)
+            h = min(hh * eta if not clipped else max(h, hh * eta), h_max)
         else:
             st["rejected"] += 1
             after_reject = True

@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""Cost of one attempt of the error-controlled stepper (embedded-pair kernel + norm reduction + host decision) beside a plain
+fused RK4 step on the same grid."""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import crdmodel_amd as crd  # noqa: E402
+
+for n in [int(v) for v in os.environ.get("SIZES", "4096,8192").split(",")]:
+    p = crd.make_params("fhn", "torus", n, 80.0, 20.0, 0.12, 1.25, ny=n)
+    dt = 0.8 * crd.stable_dt(p)
+    with crd.Slab(p) as slab:
+        slab.upload(crd.initial_conditions(crd.run_config(p)))
+        slab.step_rk4(0.0, dt, 20)
+        ms, _, _ = slab.step_rk4_timed(0.0, dt, 100)
+        y1 = slab.download()
+        for label, opts in (("capped at the stability bound (default)", {}), ("error control alone (h_max < 0)", {"h_max": -1.0})):
+            slab.upload(y1)
+            t0 = time.perf_counter()
+            st = slab.integrate_adaptive(0.0, 100 * dt, h0=dt, rtol=1e-5, atol=1e-10, **opts)
+            el = time.perf_counter() - t0
+            attempts = st["accepted"] + st["rejected"]
+            print("n=%d  fixed step %.4f ms   adaptive, %s: %d attempts (%d rejected) in %.1f ms = %.4f ms/attempt, h_last/dt = %.2f"
+                  % (n, ms / 100, label, attempts, st["rejected"], el * 1e3, el * 1e3 / attempts, st["h_last"] / dt), flush=True)
