@@ -17,6 +17,16 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def pytest_sessionstart(session):
+    """A checkout without the built library (the .so files are not tracked) gets it built here, in-tree, by the same recipe as
+    __graft_entry__.build(); an existing build is left alone."""
+    pkg = os.path.join(ROOT, "crdmodel_amd")
+    if not (os.path.exists(os.path.join(pkg, "libcrd.so")) and os.path.exists(os.path.join(pkg, "bin", "crd_run"))):
+        from crdmodel_amd.build import build
+
+        build()
+
+
 def load_golden(name):
     d = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.loads(str(d["meta"]))
