@@ -8,6 +8,7 @@ import numpy as np
 import pytest
 
 import crdmodel_amd as crd
+from crdmodel_amd import post
 from conftest import GOLDEN, ROOT, rel_err
 from oracle import crd_oracle as co
 from test_io_formats import load_like_the_plot_script
@@ -49,6 +50,9 @@ def test_driver_writes_reference_format(gpu_device, tmp_path, argv):
     assert np.array_equal(u[0], want[0, ..., 0]) and np.array_equal(v[0], want[0, ..., 1])  # IC row is exact
     assert rel_err(u, want[..., 0]) <= 1e-9 and rel_err(v, want[..., 1]) <= 1e-9
     assert np.abs(u[-1] - u[0]).max() > 0.1  # the wave actually moved
+    # the package's own Python-3 loader reads the driver's files the same way
+    run = post.load_run(tmp_path, "fhn", "torus", include_all_vars=True)
+    assert np.array_equal(run.fields["u"], u) and np.array_equal(run.fields["v"], v) and run.t_final == cfg.t_final
 
 
 def test_driver_adaptive_mode(gpu_device, tmp_path):
