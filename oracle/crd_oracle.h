@@ -9,7 +9,9 @@
  * reference is unbuildable here, and it ships no tests, golden vectors or fixtures.  This restatement is
  * therefore pinned only by (i) an independent numpy restatement (oracle/crd_oracle_np.py), (ii) analytic
  * known answers the reference's own code implies (steady states, index-space eigenfunctions), and
- * (iii) the shipped .ini parameter sets under data/ -- not by outputs of the reference itself.
+ * (iii) the shipped .ini parameter sets under data/, including the one result they state (the Goldbeter kinetics are
+ * "oscillatory when 0.28895 < beta < 0.77427", data/GoldbeterModelArgs.ini:25 -- reproduced to the digits given, as is the
+ * FHN Hopf point beta = 1 of util/FHNmodel/plot_FHNmodel_torus.py:90-92) -- not by outputs of the reference itself.
  *
  * Every function cites the reference lines it follows (paths under /root/reference/).
  */

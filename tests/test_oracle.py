@@ -143,6 +143,44 @@ def test_torus_theta_operator_is_the_curvilinear_laplacian():
     assert errs[1] < errs[0] / 3.5  # ~4x per mesh doubling
 
 
+def kinetics_jacobian_trace(f_uniform, state, eps=1e-6):
+    """Trace of the 2 x 2 Jacobian of the reaction terms at `state`, by central differences of f on uniform fields (where the
+    diffusion term vanishes identically)."""
+    s0, s1 = state
+    d0 = (f_uniform(s0 + eps, s1)[0] - f_uniform(s0 - eps, s1)[0]) / (2 * eps)
+    d1 = (f_uniform(s0, s1 + eps)[1] - f_uniform(s0, s1 - eps)[1]) / (2 * eps)
+    return d0 + d1
+
+
+def hopf_points(model, f_uniform_for_beta, brackets):
+    """beta at which the steady state of the kinetics changes stability (trace of the Jacobian = 0)."""
+    from scipy.optimize import brentq
+
+    return [brentq(lambda b: kinetics_jacobian_trace(f_uniform_for_beta(b), co.steady(model, b)), lo, hi, xtol=1e-9) for lo, hi in brackets]
+
+
+def oracle_uniform_f(model, beta):
+    p = co.make_problem(model, co.FLAT, 8, 20.0, 20.0, 0.12, beta)
+
+    def f(s0, s1):
+        y = np.empty((p.ny, p.nx, 2))
+        y[..., 0], y[..., 1] = s0, s1
+        return co.rhs(p, 0.0, y)[3, 3]
+
+    return f
+
+
+def test_known_answers_the_reference_states_about_its_kinetics():
+    """The only numbers the reference tree holds about this path's results: the Goldbeter parameter sets say the model is
+    "oscillatory when 0.28895 < beta < 0.77427" (data/GoldbeterModelArgs.ini:25, data/temp.ini:21; the torus-mapping script
+    marks 0.289 and 0.774, util/GoldbeterModel/MapOutputToTorus.py:60-63), and the FHN utilities put the Hopf bifurcation
+    at beta = 1 (util/FHNmodel/plot_FHNmodel_torus.py:90-92).  The restated kinetics reproduce both to the digits given."""
+    lo, hi = hopf_points(co.GOLDBETER, lambda b: oracle_uniform_f(co.GOLDBETER, b), [(0.2, 0.4), (0.6, 0.9)])
+    assert abs(lo - 0.28895) <= 5e-6 and abs(hi - 0.77427) <= 5e-6, (lo, hi)
+    (one,) = hopf_points(co.FHN, lambda b: oracle_uniform_f(co.FHN, b), [(0.5, 1.5)])
+    assert abs(one - 1.0) <= 1e-7, one
+
+
 def test_absorbing_rows_rule():
     """Rows j = 0 and j = ny-1 get f = 0 for both variables only while t < tBoundary (strict), :643-653."""
     meta, arr = load_golden("rhs_fhn_torus")
