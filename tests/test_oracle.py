@@ -179,6 +179,11 @@ def test_known_answers_the_reference_states_about_its_kinetics():
     assert abs(lo - 0.28895) <= 5e-6 and abs(hi - 0.77427) <= 5e-6, (lo, hi)
     (one,) = hopf_points(co.FHN, lambda b: oracle_uniform_f(co.FHN, b), [(0.5, 1.5)])
     assert abs(one - 1.0) <= 1e-7, one
+    # ... and on the right sides: "oscillatory for beta < 1, stable for beta > 1" (data/FHNmodelArgs.ini:24), oscillatory inside
+    # the Goldbeter window only
+    tr = lambda model, b: kinetics_jacobian_trace(oracle_uniform_f(model, b), co.steady(model, b))
+    assert tr(co.FHN, 0.9) > 0 > tr(co.FHN, 1.1)
+    assert tr(co.GOLDBETER, 0.5) > 0 and tr(co.GOLDBETER, 0.2) < 0 and tr(co.GOLDBETER, 0.9) < 0
 
 
 def test_absorbing_rows_rule():
