@@ -97,6 +97,7 @@ _SIGNATURES = {
     "crd_writer_open": (C.c_int, [C.POINTER(RunConfig), C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "crd_writer_write_row": (C.c_int, [_vp, _vp]),
     "crd_writer_close": (C.c_int, [_vp]),
+    "crd_device_count": (C.c_int, []),
     "crd_create": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "crd_destroy": (None, [_vp]),
     "crd_last_error": (C.c_char_p, [_vp]),

@@ -80,6 +80,16 @@ using namespace crd;
 
 extern "C" {
 
+int crd_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) {
+		(void)hipGetLastError();
+		return 0;
+	}
+	return n;
+}
+
 const char *crd_last_error(const crd_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_error.c_str(); }
 
 int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx **out)

@@ -3,6 +3,7 @@
 // reference programs (src/FHNmodel_torus.cpp:148-497 and siblings); invoked through one of the alias names
 // FHNmodel_torus / FHNmodel_flat / GoldbeterModel_torus / GoldbeterModel_flat it takes exactly one argument, like
 // they do.  Time integration is fixed-step RK4 on the GPU (libcrd) instead of adaptive ARKode.
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -110,6 +111,31 @@ int die(const char *what, int rc, crd_ctx *ctx)
 
 }  // namespace
 
+// Rank and size an MPI launcher gave this process through its environment (no MPI library is linked).
+struct Launcher {
+	int rank = 0, size = 1;
+	const char *kind = "";
+};
+static Launcher detect_launcher()
+{
+	static const struct {
+		const char *rank, *size, *kind;
+	} known[] = {{"OMPI_COMM_WORLD_RANK", "OMPI_COMM_WORLD_SIZE", "Open MPI"},
+	             {"PMI_RANK", "PMI_SIZE", "MPICH / Hydra"},
+	             {"MV2_COMM_WORLD_RANK", "MV2_COMM_WORLD_SIZE", "MVAPICH"}};
+	Launcher l;
+	for (const auto &k : known) {
+		const char *r = std::getenv(k.rank), *n = std::getenv(k.size);
+		if (r && n && std::atoi(n) >= 1 && std::atoi(r) >= 0 && std::atoi(r) < std::atoi(n)) {
+			l.rank = std::atoi(r);
+			l.size = std::atoi(n);
+			l.kind = k.kind;
+			break;
+		}
+	}
+	return l;
+}
+
 int main(int argc, char *argv[])
 {
 	Options o;
@@ -154,6 +180,12 @@ int main(int argc, char *argv[])
 		if (o.model < 0 || o.surface < 0 || o.ini.empty() || o.precision == -2 || o.stepper == -2) usage(argv[0], false);
 	}
 
+	// Started by an MPI launcher the way the reference is (`mpirun -np N <exe> <ini>`, util/ShellScripts/run*.sh)?  This
+	// program needs one process only: rank 0 drives N phi-slabs, one per GPU, and writes the N subdomain file sets the N
+	// reference ranks would; the other ranks have nothing to do.
+	const Launcher launcher = detect_launcher();
+	if (launcher.size > 1 && launcher.rank != 0) return 0;
+
 	crd_run_config cfg;
 	char err[512];
 	int rc = crd_config_load_ini(o.ini.c_str(), o.model, o.surface, &cfg, err, sizeof err);
@@ -162,6 +194,13 @@ int main(int argc, char *argv[])
 		return 1;
 	}
 	if (o.gpus > 0) cfg.n_gpus = o.gpus;
+	else if (launcher.size > 1 && cfg.n_gpus == 1) {
+		cfg.n_gpus = launcher.size;
+		if (o.devices <= 0) o.devices = std::max(1, std::min(launcher.size, crd_device_count()));
+		if (!o.quiet)
+			std::cout << "\n" << launcher.kind << " started " << launcher.size << " ranks: rank 0 drives " << launcher.size << " phi-slabs on " << o.devices
+			          << " GPU(s), the other ranks exit\n";
+	}
 	if (o.dt > 0) cfg.dt = o.dt;
 	if (o.stepper >= 0) cfg.stepper = o.stepper;
 	if (o.precision >= 0) cfg.params.precision = o.precision;

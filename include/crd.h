@@ -150,6 +150,9 @@ int crd_writer_close(crd_writer *w);
  * (src/FHNmodel_torus.cpp:97-122,708-772,953-997).  Not thread-safe; calls on one context must be serialised.
  * --------------------------------------------------------------------------------------------------------- */
 
+/* HIP devices visible to this process (0 when there is none or the runtime cannot start). */
+int crd_device_count(void);
+
 /* slab / n_slabs: which phi-slab of the global grid this context owns; device: HIP device ordinal. */
 int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx **out);
 void crd_destroy(crd_ctx *ctx);

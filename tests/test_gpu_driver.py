@@ -114,3 +114,17 @@ def test_config_c1_flat_256_driver(gpu_device, tmp_path):
     u, meta = load_like_the_plot_script(tmp_path, "FHNmodel_flat", "u")
     assert (meta["nx"], meta["ny"], meta["nt"], meta["xmax"]) == (256, 256, 5, 20.0)
     assert rel_err(u, np.stack(frames)[..., 0]) <= 1e-9
+
+
+def test_driver_started_by_an_mpi_launcher(gpu_device, tmp_path):
+    """Rank 0 of an `mpirun -np 2` start (launcher environment emulated) drives two phi-slabs and writes the two subdomain file
+    sets the reference's two ranks would; same numbers as the one-slab run."""
+    cfg = crd.load_ini(INI, "fhn", "torus")
+    r = subprocess.run([os.path.join(BIN, "FHNmodel_torus"), INI], cwd=tmp_path, capture_output=True, text=True, timeout=300,
+                       env=dict(os.environ, PMI_RANK="0", PMI_SIZE="2"))
+    assert r.returncode == 0, r.stderr
+    assert "started 2 ranks: rank 0 drives 2 phi-slabs" in r.stdout
+    run = post.load_run(tmp_path, "fhn", "torus", include_all_vars=True)
+    assert run.subdomains.shape == (2, 4)
+    want = oracle_outputs(cfg)
+    assert rel_err(run.fields["u"], want[..., 0]) <= 1e-9 and rel_err(run.fields["v"], want[..., 1]) <= 1e-9

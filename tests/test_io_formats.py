@@ -86,3 +86,13 @@ def test_driver_command_line_surface(tmp_path):
     assert r.returncode == 1 and "betaMin" in r.stderr
     r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", os.path.join(INI, "small_run.ini")], capture_output=True, text=True)
     assert r.returncode == 1 and "--surface" in r.stderr
+
+
+def test_driver_under_an_mpi_launcher_leaves_the_work_to_rank_zero(tmp_path):
+    """`mpirun -np N <exe> <ini>` is how the reference is started (util/ShellScripts/runFHNmodelTorus.sh:6).  This driver is
+    one process for all GPUs: every rank but 0 exits at once, successfully and without touching the output directory."""
+    for env in (dict(PMI_RANK="1", PMI_SIZE="2"), dict(OMPI_COMM_WORLD_RANK="3", OMPI_COMM_WORLD_SIZE="4")):
+        r = subprocess.run([os.path.join(BIN, "FHNmodel_torus"), os.path.join(INI, "small_run.ini")], cwd=tmp_path, capture_output=True, text=True,
+                           env=dict(os.environ, **env), timeout=60)
+        assert r.returncode == 0 and r.stdout == "" and r.stderr == ""
+        assert os.listdir(tmp_path) == []
