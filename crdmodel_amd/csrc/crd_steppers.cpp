@@ -92,9 +92,9 @@ int staged_step_multi(crd_ctx *const *cs, int n, double t, double dt, bool timed
 //   compute: interior [B, nyl-B) (needs neither ghost rows nor the bands)         -> record interior
 // and so is the first step of the next cycle
 //   compute: rows [4, nyl-4), which read owned rows only, straight after the interior sweep
-//   compute: [wait halo] rows [-e, 4) and [nyl-4, nyl+e), the ones that read ghost rows, in one small launch
-// so the exchange has two sweeps to hide under.  Per step that is 1.5 launches and a quarter of an RCCL group on the host,
-// against 3 launches + 1 group for a per-step exchange.
+//   compute: [wait halo] rows [-e, 4) and [nyl-4, nyl+e), the ones that read ghost rows, in one small launch (e = kGhost - 4)
+// so the exchange has two sweeps to hide under.  Per step that is 1 + 2 / kExchangeEvery launches and 1 / kExchangeEvery of an
+// RCCL group on the host, against 3 launches + 1 group for a per-step exchange.
 constexpr int kFusedBand = 32;
 static_assert(kFusedBand >= kGhost, "the edge bands must contain every row the exchange sends");
 
@@ -284,8 +284,12 @@ int crd_set_stepper(crd_ctx *c, int stepper)
 {
 	if (!c) return CRD_EINVAL;
 	if (stepper != CRD_STEPPER_AUTO && stepper != CRD_STEPPER_STAGED && stepper != CRD_STEPPER_FUSED) return fail(c, CRD_EINVAL, "unknown stepper");
-	if (stepper == CRD_STEPPER_FUSED && !fused_step_supported(c->p.precision, c->desc)) return fail(c, CRD_EINVAL, "fused stepper not available for this configuration");
+	const int before = c->stepper;
 	c->stepper = stepper;
+	if (stepper == CRD_STEPPER_FUSED && resolve_stepper(c) < 0) {
+		c->stepper = before;
+		return fail(c, CRD_EINVAL, "fused stepper not available for this configuration (slab too short)");
+	}
 	return CRD_OK;
 }
 

@@ -41,7 +41,7 @@ enum { CRD_PRECISION_F64 = 0, CRD_PRECISION_F32 = 1 };
 enum {
 	CRD_STEPPER_AUTO = 0,
 	CRD_STEPPER_STAGED = 1, /* four stage kernels per step, one halo row exchanged per stage */
-	CRD_STEPPER_FUSED = 2   /* one kernel per step (all four stages on chip); multi-slab: 16 halo rows every 4 steps */
+	CRD_STEPPER_FUSED = 2   /* one kernel per step (all four stages on chip); multi-slab: 32 halo rows every 8 steps; slabs shorter than that use the staged kernels */
 };
 
 /* Halo transport between the slabs of one run. */
