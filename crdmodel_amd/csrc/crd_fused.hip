@@ -2,7 +2,8 @@
 // stage updates happen on chip, so a grid-point-step costs one read and one write of the state (32 B in fp64) instead
 // of the 256 B the four stage kernels of crd_kernels.hip move.  Same arithmetic per point as the staged stepper.
 //
-// Structure (no LDS, no barriers, no MFMA): every WAVEFRONT is an independent work item.  It owns a strip of 64
+// Structure (no LDS, no MFMA; no data passes between wavefronts -- the one barrier per iteration only keeps the four
+// wavefronts of a block in step): every WAVEFRONT is an independent work item.  It owns a strip of 64
 // consecutive theta columns -- one column per lane, 56 valid outputs in the middle and a 4-column apron on each side
 // that is recomputed redundantly -- and marches along phi through a chunk of rows as a 4-deep software pipeline:
 //   iteration m:  take row p        (state y0, fetched four iterations earlier)
