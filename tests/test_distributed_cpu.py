@@ -98,6 +98,32 @@ def _worker(rank, world, port, result_dir):
         ref = co.rk4(gp, y_global, 0.0, dt, nsteps)[js:je + 1]
         assert np.array_equal(y, ref)
 
+        # --- the fused stepper's communication-avoiding cycle: 32 ghost rows of BOTH fields exchanged once per 8 RK4 steps; in
+        #     between every rank steps its whole extended block and lets stale data creep in from the block's ends, 4 rows per
+        #     step (one per RHS evaluation), which after 8 steps has consumed exactly the ghost region.  Row-independent
+        #     problem (beta constant, no absorbing rows) so that a block can be stepped as a small periodic problem of its own;
+        #     the owned rows must equal the whole-domain RK4 bit for bit. ---------------------------------------------------
+        every, halo = 8, 32
+        ny2 = 40 * world
+        gq = co.make_problem(co.FHN, co.TORUS, nx, L, W, D, beta, ny=ny2)
+        yq = np.random.default_rng(9).standard_normal((ny2, nx, 2))
+        js2, je2 = crd.slab_extents(ny2, rank, world)
+        nyl2 = je2 - js2 + 1
+        assert nyl2 >= halo
+        block = co.make_problem(co.FHN, co.TORUS, nx, L, W, D, beta, ny=nyl2 + 2 * halo)
+        block.dy = gq.dy  # the block keeps the whole grid's phi spacing
+        ext = np.ascontiguousarray(yq[np.arange(js2 - halo, je2 + 1 + halo) % ny2])
+        dt2, cycles = 0.02, 2
+        for cycle in range(cycles):
+            ext = co.rk4(block, ext, 0.0, dt2, every)
+            for var in (0, 1):  # refresh the ghost rows of both fields through the library's plan
+                plane = np.ascontiguousarray(ext[..., var])
+                _exchange(dist, plane, nyl2, halo, rank, world, crd)
+                ext[..., var] = plane
+        refq = co.rk4(gq, yq, 0.0, dt2, every * cycles)
+        assert np.array_equal(ext[halo:halo + nyl2], refq[js2:je2 + 1])
+        assert np.array_equal(ext, refq[np.arange(js2 - halo, je2 + 1 + halo) % ny2])  # and the ghosts are fresh again
+
         # --- the aggregation bench.py does: max over ranks of the elapsed time --------------------------------
         import torch
 
