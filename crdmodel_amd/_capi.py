@@ -106,6 +106,9 @@ _SIGNATURES = {
     "crd_comm_attach_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
     "crd_comm_unique_id": (C.c_int, [_vp]),
     "crd_comm_init_rccl": (C.c_int, [_vp, _vp]),
+    "crd_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "crd_halo_exchange": (C.c_int, [_vp, C.c_int]),
+    "crd_state_download_rows": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp]),
     "crd_halo_plan": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(HaloOp)]),
     "crd_state_upload": (C.c_int, [_vp, _vp, C.c_int]),
     "crd_state_download": (C.c_int, [_vp, _vp, C.c_int]),

@@ -293,6 +293,60 @@ int crd_comm_init_rccl(crd_ctx *c, const void *id128)
 	return CRD_OK;
 }
 
+int crd_comm_info(const crd_ctx *c, int *halo, int *ranks, int *rank)
+{
+	if (!c) return CRD_EINVAL;
+	if (halo) *halo = c->halo;
+	int n = c->n_slabs, r = c->slab;
+	if (c->halo == CRD_HALO_RCCL) {  // what the communicator itself says, not what this context was created with
+		NCCL_TRY(const_cast<crd_ctx *>(c), g_rccl.CommCount(c->nccl, &n));
+		NCCL_TRY(const_cast<crd_ctx *>(c), g_rccl.CommUserRank(c->nccl, &r));
+	} else if (c->halo == CRD_HALO_SELF) {
+		n = 1;
+		r = 0;
+	}
+	if (ranks) *ranks = n;
+	if (rank) *rank = r;
+	return CRD_OK;
+}
+
+int crd_halo_exchange(crd_ctx *c, int depth)
+{
+	if (!c) return CRD_EINVAL;
+	if (depth < 1 || depth > kGhost || depth > c->nyl) return fail(c, CRD_EINVAL, "halo depth out of range (1 .. 32, at most the slab's rows)");
+	if (c->halo < 0) return fail(c, CRD_ESTATE, "multi-slab context is not wired (crd_comm_attach_local / crd_comm_init_rccl)");
+	if (c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "LOCAL groups exchange inside crd_group_step_rk4");
+	if (int rc = set_device(c)) return rc;
+	if (c->halo == CRD_HALO_SELF) {
+		// a single slab wraps inside the kernels; fill the ghost rows with the periodic image anyway so that they can be read back
+		const size_t bytes = (size_t)depth * (size_t)c->nx * c->real_size;
+		for (int f = 0; f < 2; f++) {
+			void *pl = c->plane[crd_ctx::Y][f];
+			HIP_TRY(c, hipMemcpyAsync(c->row_ptr(pl, -depth), c->row_ptr(pl, c->nyl - depth), bytes, hipMemcpyDeviceToDevice, c->compute));
+			HIP_TRY(c, hipMemcpyAsync(c->row_ptr(pl, c->nyl), c->row_ptr(pl, 0), bytes, hipMemcpyDeviceToDevice, c->compute));
+		}
+		HIP_TRY(c, hipStreamSynchronize(c->compute));
+		return CRD_OK;
+	}
+	crd_ctx *one[1] = {c};
+	if (int rc = prime_halo(one, 1, crd_ctx::Y, depth, true)) return rc;
+	HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+	HIP_TRY(c, hipStreamSynchronize(c->comm));
+	HIP_TRY(c, hipStreamSynchronize(c->compute));
+	return CRD_OK;
+}
+
+int crd_state_download_rows(crd_ctx *c, int var, int64_t row_begin, int64_t row_count, void *host)
+{
+	if (!c || !host) return CRD_EINVAL;
+	if ((var != 0 && var != 1) || row_count < 0 || row_begin < -kGhost || row_begin + row_count > (int64_t)c->nyl + kGhost) return fail(c, CRD_EINVAL, "rows outside the plane");
+	if (int rc = set_device(c)) return rc;
+	if (row_count == 0) return CRD_OK;
+	HIP_TRY(c, hipMemcpyAsync(host, c->row_ptr(c->plane[crd_ctx::Y][var], row_begin), (size_t)row_count * (size_t)c->nx * c->real_size, hipMemcpyDeviceToHost, c->compute));
+	HIP_TRY(c, hipStreamSynchronize(c->compute));
+	return CRD_OK;
+}
+
 int crd_state_upload(crd_ctx *c, const void *y, int host_is_f64)
 {
 	if (!c || !y) return CRD_EINVAL;

@@ -28,6 +28,8 @@ struct RcclApi {
 	decltype(&ncclSend) Send = nullptr;
 	decltype(&ncclRecv) Recv = nullptr;
 	decltype(&ncclAllReduce) AllReduce = nullptr;
+	decltype(&ncclCommCount) CommCount = nullptr;
+	decltype(&ncclCommUserRank) CommUserRank = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 	std::string error;
 

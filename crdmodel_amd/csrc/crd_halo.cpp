@@ -36,6 +36,8 @@ bool RcclApi::load()
 	Send = reinterpret_cast<decltype(Send)>(sym("ncclSend"));
 	Recv = reinterpret_cast<decltype(Recv)>(sym("ncclRecv"));
 	AllReduce = reinterpret_cast<decltype(AllReduce)>(sym("ncclAllReduce"));
+	CommCount = reinterpret_cast<decltype(CommCount)>(sym("ncclCommCount"));
+	CommUserRank = reinterpret_cast<decltype(CommUserRank)>(sym("ncclCommUserRank"));
 	GetErrorString = reinterpret_cast<decltype(GetErrorString)>(sym("ncclGetErrorString"));
 	if (!error.empty()) {
 		handle = nullptr;

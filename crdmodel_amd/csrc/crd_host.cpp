@@ -203,9 +203,15 @@ int crd_initial_conditions(const crd_run_config *cfg, int64_t js, int64_t je, do
 	int rc = crd_grid_from_params(&p, &g);
 	if (rc != CRD_OK) return rc;
 	if (js < 0 || je < js || je >= g.ny) return CRD_EINVAL;
+	// The stable state enters only the rules that start from it (the reference computes Us, Vs / reads Zs, Ys for these
+	// and never touches them under the uniform and varyBeta rules, so an unused `beta` without a fixed point must not matter).
+	const bool needs_steady = (p.model == CRD_MODEL_FHN) ? !((p.surface == CRD_SURFACE_TORUS) ? (p.vary_beta != 0) : (p.vary_beta == 1))
+	                                                     : (p.vary_beta != 1);
 	double s0 = 0.0, s1 = 0.0;
-	rc = crd_steady_state(p.model, p.beta, &s0, &s1);
-	if (rc != CRD_OK) return rc;
+	if (needs_steady) {
+		rc = crd_steady_state(p.model, p.beta, &s0, &s1);
+		if (rc != CRD_OK) return rc;
+	}
 
 	// Rectangle limits: src/FHNmodel_torus.cpp:199-200,285-300; flat src/FHNmodel_flat.cpp:280-282.
 	const double wave_length = (g.ymax - g.ymin) * cfg->wave_length;

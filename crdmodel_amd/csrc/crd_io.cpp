@@ -260,16 +260,20 @@ namespace {
 // printf's digits (checked against snprintf on 2e6 random bit patterns, tests/test_io_formats.py re-checks the bytes) and
 // is ~3x faster; text output dominates a run on a large grid (1.6 GB per output time at 8192^2), hence the thread fan-out
 // in crd_writer_write_row as well.
-inline char *put_e16(char *out, double v)
+// The longest value is 25 characters (" -1.2345678901234567e-308": space, sign, 18 mantissa characters, 'e', sign, three
+// exponent digits); buffers are sized with kMaxValueChars per value and the true end of the buffer bounds every write.
+constexpr size_t kMaxValueChars = 32;
+inline char *put_e16(char *out, char *end, double v)
 {
+	if (end - out < (ptrdiff_t)kMaxValueChars) return out;  // cannot happen with buffers sized by kMaxValueChars; never write past the end
 	*out++ = ' ';
 #if defined(__cpp_lib_to_chars) && __cpp_lib_to_chars >= 201611L
 	if (std::isfinite(v)) {
-		auto r = std::to_chars(out, out + 30, v, std::chars_format::scientific, 16);
+		auto r = std::to_chars(out, end, v, std::chars_format::scientific, 16);
 		if (r.ec == std::errc()) return r.ptr;
 	}
 #endif
-	return out + std::snprintf(out, 31, "%.16e", v);
+	return out + std::snprintf(out, (size_t)(end - out), "%.16e", v);
 }
 
 // Host cores this process may use: affinity mask capped by the cgroup CPU quota.
@@ -341,7 +345,7 @@ extern "C" int crd_writer_write_row(crd_writer *w, const double *y_aos)
 	const int64_t per_thread = 1 << 16;  // values formatted by one thread per round (<= 1.6 MB of text)
 	const int T = w->threads;
 	w->text.resize((size_t)T);
-	for (auto &b : w->text) b.resize((size_t)per_thread * 24 + 8);
+	for (auto &b : w->text) b.resize((size_t)per_thread * kMaxValueChars);
 	std::vector<size_t> used((size_t)T);
 	auto fan_out = [&](int active, auto &&fn) {
 		std::vector<std::thread> pool;
@@ -366,8 +370,8 @@ extern "C" int crd_writer_write_row(crd_writer *w, const double *y_aos)
 			const int active = (int)std::min<int64_t>(T, (n - q0 + per_thread - 1) / per_thread);
 			fan_out(active, [&](int t) {  // phase 1: format
 				const int64_t a = q0 + per_thread * t, b = std::min<int64_t>(a + per_thread, n);
-				char *c = w->text[(size_t)t].data();
-				for (int64_t q = a; q < b; q++) c = put_e16(c, y_aos[2 * q + var]);
+				char *c = w->text[(size_t)t].data(), *end = c + w->text[(size_t)t].size();
+				for (int64_t q = a; q < b; q++) c = put_e16(c, end, y_aos[2 * q + var]);
 				used[(size_t)t] = (size_t)(c - w->text[(size_t)t].data());
 			});
 			// phase 2: append in order.  (Writes to one file serialise on the inode lock, so concurrent pwrites from the

@@ -214,8 +214,8 @@ int main(int argc, char *argv[])
 	const int G = cfg.n_gpus;
 	const int ndev = o.devices > 0 ? o.devices : G;
 
-	double s0 = 0, s1 = 0;
-	if ((rc = crd_steady_state(cfg.params.model, cfg.params.beta, &s0, &s1)) != CRD_OK) return die("crd_steady_state", rc, nullptr);
+	double s0 = 0, s1 = 0;  // banner only, and only printed for a constant beta (src/FHNmodel_torus.cpp:268-271)
+	if (cfg.params.vary_beta == 0 && (rc = crd_steady_state(cfg.params.model, cfg.params.beta, &s0, &s1)) != CRD_OK) return die("crd_steady_state", rc, nullptr);
 
 	// Output cadence (src/FHNmodel_torus.cpp:415-429): Nt outputs dTout apart; every interval is an integer number of
 	// equal RK4 steps no longer than the requested / stable step.
@@ -300,8 +300,13 @@ int main(int argc, char *argv[])
 			rc = crd_group_step_rk4(ctx.data(), G, t, dt, steps_per_output);
 		}
 		for (int k = 0; k < G && rc == CRD_OK; k++) rc = crd_state_download(ctx[(size_t)k], buf[(size_t)k].data(), 1);
+		// the reference stops at the first failing ARKode call on ANY rank (src/FHNmodel_torus.cpp:424-435): look at every slab
 		double peak = 0;
-		if (rc == CRD_OK) rc = crd_state_max_abs(ctx[0], &peak);
+		for (int k = 0; k < G && rc == CRD_OK; k++) {
+			double pk = 0;
+			rc = crd_state_max_abs(ctx[(size_t)k], &pk);
+			if (!(pk <= peak)) peak = pk;  // keeps a NaN
+		}
 		if (rc != CRD_OK || !std::isfinite(peak)) {
 			if (rc != CRD_OK) die("crd_group_step_rk4", rc, ctx[0]);
 			std::cerr << "Solver failure, stopping integration\n";  // src/FHNmodel_torus.cpp:433

@@ -124,13 +124,15 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
-				HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
+				// (nothing to record: the next step runs on the same stream; only the band stream, when there is one, needs
+				// ev_interior, and it is recorded by the step in front of the cycle's last one -- see below)
+				if (c->bands_on_own_stream && q == kExchangeEvery - 2) HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
 				continue;
 			}
 			// First step after an exchange.  Output rows [kStepHalo, nyl - kStepHalo) read owned rows only, so they are launched
 			// as soon as the bands of the previous step are in: the exchange gets this sweep as extra time to land.
 			const bool split = c->nyl >= 4 * kFusedBand;
-			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));
+			if (c->bands_on_own_stream) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));  // otherwise the bands ran on this very stream
 			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kStepHalo, c->nyl - kStepHalo, 0, 0, c->compute));
 			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
 			if (c->halo == CRD_HALO_LOCAL) {
@@ -142,7 +144,7 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			// the rows that read ghost rows: [-ext, kStepHalo) and [nyl - kStepHalo, nyl + ext) in one launch
 			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, kStepHalo, c->nyl - kStepHalo, c->nyl + ext, c->compute));
 			else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
-			HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
+			if (c->bands_on_own_stream && q == kExchangeEvery - 2) HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
 		}
 		return CRD_OK;
 	}
@@ -157,7 +159,8 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));
 			HIP_TRY(c, hipStreamWaitEvent(bs, c->ev_halo, 0));
 		}
-		HIP_TRY(c, hipStreamWaitEvent(bs, c->ev_interior, 0));  // previous step done: its output is read, its input plane is overwritten
+		// previous step done (its output is read, its input plane is overwritten): stream order, unless the bands have a stream of their own
+		if (c->bands_on_own_stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->ev_interior, 0));
 		if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, kFusedBand, c->nyl - kFusedBand, c->nyl, bs));
 		else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, bs));
 		HIP_TRY(c, hipEventRecord(c->ev_edges, bs));
@@ -170,7 +173,6 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			const FusedCall call = make_fused_call(c, t, dt, src, dst);
 			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kFusedBand, c->nyl - kFusedBand, 0, 0, c->compute));
 		}
-		HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
 	}
 	return CRD_OK;
 }
@@ -220,7 +222,9 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		for (int64_t s = 0; s < nsteps; s++) {
 			const double t = t0 + (double)s * dt;
 			hipEvent_t *kb = nullptr, *ke = nullptr;
-			if (timed_launches && timed < kMaxTimedLaunches && (s * kMaxTimedLaunches / std::max<int64_t>(nsteps, 1)) >= timed) {
+			// every fourth step at most: an event pair around EVERY launch of a short run would sit inside the region being timed
+			const int64_t want = std::min<int64_t>(kMaxTimedLaunches, std::max<int64_t>(1, nsteps / 4));
+			if (timed_launches && timed < want && (s * want / std::max<int64_t>(nsteps, 1)) >= timed && (s % 4 == 1 || nsteps < 4)) {
 				kb = &c->ev_k[(size_t)(2 * timed)];
 				ke = &c->ev_k[(size_t)(2 * timed + 1)];
 				timed++;

@@ -192,6 +192,12 @@ class Slab:
         self._check(lib().crd_state_download(self._h, y.ctypes.data, 1 if y.dtype == np.float64 else 0), "crd_state_download")
         return y
 
+    def download_rows(self, var, row_begin, row_count):
+        """Rows [row_begin, row_begin + row_count) of one field of the resident state, ghost rows included (device precision)."""
+        rows = np.empty((row_count, self.nx), dtype=self.dtype)
+        self._check(lib().crd_state_download_rows(self._h, var, row_begin, row_count, rows.ctypes.data), "crd_state_download_rows")
+        return rows
+
     # -- the RHS callback --------------------------------------------------------------------------------------
     def f(self, t, y, out=None):
         """ydot = f(t, y) for this slab's AoS vector (host arrays in the device precision).  With y and `out` both over
@@ -245,6 +251,16 @@ class Slab:
         buf = C.create_string_buffer(bytes(unique_id), 128)
         self._check(lib().crd_comm_init_rccl(self._h, buf), "crd_comm_init_rccl")
 
+    def comm_info(self):
+        """(transport, ranks, rank): transport is 'self' / 'local' / 'rccl'; for RCCL the last two come from the communicator."""
+        halo, ranks, rank = C.c_int(), C.c_int(), C.c_int()
+        self._check(lib().crd_comm_info(self._h, C.byref(halo), C.byref(ranks), C.byref(rank)), "crd_comm_info")
+        return {0: "self", 1: "local", 2: "rccl"}.get(halo.value, "unwired"), ranks.value, rank.value
+
+    def halo_exchange(self, depth=32):
+        """One exchange of `depth` ghost rows of both fields with the ring neighbours, outside any step; waits for it."""
+        self._check(lib().crd_halo_exchange(self._h, depth), "crd_halo_exchange")
+
 
 class PinnedArray:
     """A numpy array over page-locked host memory from crd_host_alloc (freed with the object)."""
@@ -289,8 +305,8 @@ class LocalGroup:
         for s in self.slabs:
             s.upload(y[s.js:s.je + 1])
 
-    def download(self):
-        return np.concatenate([s.download() for s in self.slabs], axis=0)
+    def download(self, dtype=np.float64):
+        return np.concatenate([s.download(dtype) for s in self.slabs], axis=0)
 
     def f(self, t, y):
         """ydot = f(t, y) on the whole grid, evaluated slab by slab with halos exchanged between the slabs' vectors."""

@@ -168,6 +168,20 @@ int crd_comm_attach_local(crd_ctx *const *ctxs, int n_slabs);
 int crd_comm_unique_id(void *id128);
 int crd_comm_init_rccl(crd_ctx *ctx, const void *id128);
 
+/* What the context's transport is and, for RCCL, what the communicator itself reports (ncclCommCount / ncclCommUserRank):
+ * halo = CRD_HALO_* (-1 while a multi-slab context is not wired yet), ranks / rank of the ring.  Any pointer may be NULL. */
+int crd_comm_info(const crd_ctx *ctx, int *halo, int *ranks, int *rank);
+
+/* ONE halo exchange of the resident state, outside any step: fills ghost rows [-depth, 0) and [nyl, nyl+depth) of both
+ * fields from the ring neighbours (the N/S half of Exchange(), src/FHNmodel_torus.cpp:775-950, at the depth the fused
+ * stepper uses) and waits for it.  1 <= depth <= 32.  Every rank of an RCCL run must make the same call.  Together with
+ * crd_state_download_rows it lets a host program verify the transport (ghost rows == the neighbours' owned rows). */
+int crd_halo_exchange(crd_ctx *ctx, int depth);
+
+/* Rows [row_begin, row_begin + row_count) of ONE field (var 0 / 1) of the resident state, ghost rows included
+ * (-32 <= row_begin, row_begin + row_count <= nyl + 32), as contiguous rows of nx reals in the DEVICE precision. */
+int crd_state_download_rows(crd_ctx *ctx, int var, int64_t row_begin, int64_t row_count, void *rows_host);
+
 /* The ring protocol of one halo exchange, as data: the four point-to-point operations slab `slab` of `n_slabs` issues,
  * in issue order, to fill its ghost rows [-depth, 0) and [nyl, nyl+depth) from its periodic phi neighbours (replaces the
  * N/S half of Exchange(), src/FHNmodel_torus.cpp:775-950; the E/W half disappears because a slab spans all of theta).

@@ -149,6 +149,34 @@ int main(int argc, char **argv)
 		CHECK(v == y[2 * ((size_t)512 * 600 - 1)]);
 		std::fclose(f);
 	}
+	{  // every value at the widest text form, 25 characters (" -1.5000000000000000e-200"): a whole multi-thread row of them, then
+	   // +-1e+-200, subnormals and non-finite values mixed; each row must read back exactly
+		crd_run_config wide = cfg;
+		wide.params.nx = 512;
+		wide.params.ny = 512;
+		wide.params.model = CRD_MODEL_FHN;
+		wide.params.surface = CRD_SURFACE_FLAT;
+		wide.params.surface_length = wide.params.surface_width = 20.0;
+		wide.include_all_vars = 1;
+		crd_writer *ww = nullptr;
+		CHECK(crd_writer_open(&wide, dir.c_str(), 0, 1, &ww) == CRD_OK && ww);
+		std::vector<double> y((size_t)2 * 512 * 512, -1.5e-200);
+		CHECK(crd_writer_write_row(ww, y.data()) == CRD_OK);
+		const double odd[8] = {-1e-200, -1e200, 1e-200, 1e200, -4.9406564584124654e-324, -1.7976931348623157e308, -INFINITY, NAN};
+		for (size_t q = 0; q < y.size(); q++) y[q] = odd[q % 8];
+		CHECK(crd_writer_write_row(ww, y.data()) == CRD_OK);
+		CHECK(crd_writer_close(ww) == CRD_OK);
+		FILE *f = std::fopen((dir + "/FHNmodel_flat_u.000.txt").c_str(), "r");
+		CHECK(f);
+		double v = 0.0;
+		for (size_t q = 0; q < (size_t)512 * 512; q++) CHECK(std::fscanf(f, "%lf", &v) == 1 && v == -1.5e-200);
+		for (size_t q = 0; q < (size_t)512 * 512; q++) {
+			CHECK(std::fscanf(f, "%lf", &v) == 1);
+			const double want = odd[(2 * q) % 8];
+			CHECK(std::isnan(want) ? std::isnan(v) : v == want);
+		}
+		std::fclose(f);
+	}
 	crd_writer *w = nullptr;
 	CHECK(crd_writer_open(&cfg, (dir + "/no/such/dir").c_str(), 0, 1, &w) != CRD_OK && w == nullptr);
 	CHECK(crd_writer_open(&cfg, dir.c_str(), 2, 2, &w) != CRD_OK);
