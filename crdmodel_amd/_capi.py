@@ -83,6 +83,13 @@ class RunConfig(C.Structure):
     ]
 
 
+class LaunchPlan(C.Structure):
+    """crd_launch_plan"""
+
+    _fields_ = [("autotune", C.c_int32), ("tuned", C.c_int32), ("one_round", C.c_int32), ("xcd_mapping", C.c_int32), ("rows", C.c_int32),
+                ("reserved", C.c_int32), ("ms_default", C.c_double), ("ms_chosen", C.c_double)]
+
+
 # name -> (restype, argtypes); the test suite checks this table against include/crd.h symbol by symbol.
 _vp = C.c_void_p
 _SIGNATURES = {
@@ -131,6 +138,8 @@ _SIGNATURES = {
     "crd_dominant_kernel_rows": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "crd_dominant_kernel_name": (C.c_char_p, [_vp]),
     "crd_state_max_abs": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "crd_set_autotune": (C.c_int, [_vp, C.c_int]),
+    "crd_get_launch_plan": (C.c_int, [_vp, C.POINTER(LaunchPlan)]),
 }
 
 _lib = None

@@ -122,6 +122,7 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	c->plane_bytes = (size_t)(c->nyl + 2 * kGhost) * (size_t)c->nx * c->real_size;
 	c->halo = n_slabs == 1 ? CRD_HALO_SELF : -1;  // multi-slab contexts must be wired before use
 	if (const char *e = std::getenv("CRD_BAND_STREAM")) c->bands_on_own_stream = std::atoi(e) != 0;
+	if (const char *e = std::getenv("CRD_AUTOTUNE")) c->plan.autotune = c->plan_embed.autotune = std::atoi(e) != 0;
 
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bail(fail(c, CRD_EHIP, "no HIP device available (libcrd has no CPU fallback)"));
@@ -165,6 +166,8 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	build_coefficients(c->p, c->g, &co);
 	std::vector<double> brow;
 	build_beta_rows(c->p, c->g, c->js - kGhost, c->je + 1 + kGhost, &brow);
+	if (p->model == CRD_MODEL_GOLDBETER)  // the kernels take the row-constant source term v0 + v1 b(j) of src/GoldbeterModel_torus.cpp:715 ready-made
+		for (double &b : brow) b = std::fma(kGbV1, b, kGbV0);
 	if ((rc = upload_table(c, co.cA, &c->cA)) || (rc = upload_table(c, co.cP, &c->cP)) || (rc = upload_table(c, brow, &c->brow))) return bail(rc);
 
 	SlabDesc &d = c->desc;
@@ -557,6 +560,27 @@ int crd_synchronize(crd_ctx *c)
 	HIP_TRY(c, hipStreamSynchronize(c->comm));
 	if (c->band) HIP_TRY(c, hipStreamSynchronize(c->band));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));
+	return CRD_OK;
+}
+
+int crd_set_autotune(crd_ctx *c, int on)
+{
+	if (!c) return CRD_EINVAL;
+	c->plan.autotune = c->plan_embed.autotune = on != 0;
+	if (!on) c->plan.tuned = c->plan_embed.tuned = 0;  // back to the plain plan
+	return CRD_OK;
+}
+
+int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
+{
+	if (!c || !out) return CRD_EINVAL;
+	out->autotune = c->plan.autotune;
+	out->tuned = c->plan.tuned;
+	out->one_round = c->plan.one_round;
+	out->xcd_mapping = c->plan.remap;
+	out->rows = c->plan.rows;
+	out->ms_default = c->plan.ms_default;
+	out->ms_chosen = c->plan.ms_best;
 	return CRD_OK;
 }
 

@@ -90,6 +90,7 @@ struct crd_ctx {
 
 	crd::SlabDesc desc{};
 	int stepper = CRD_STEPPER_AUTO;
+	crd::FusedPlan plan{}, plan_embed{};  // launch plans of the one-launch step (plain / with the embedded error estimate)
 
 	int halo = CRD_HALO_SELF;
 	std::vector<crd_ctx *> group;  // LOCAL: all contexts of the run, by slab index

@@ -71,11 +71,15 @@ __device__ __forceinline__ float fmadd(float a, float b, float c) { return __bui
 // 1 / x for a positive, normal x well inside the exponent range (here x >= K2^2 KR^2 KA^4 = 2.6): the hardware estimate
 // refined by two Newton steps, i.e. the core of the compiler's division sequence without the scaling and special-case
 // instructions around it (11 -> 5 instructions per reciprocal; the result is within 1 ulp of the rounded quotient).
+#ifndef CRD_RCP_NEWTON
+#define CRD_RCP_NEWTON 1
+#endif
 __device__ __forceinline__ double reciprocal(double x)
 {
 	double r = __builtin_amdgcn_rcp(x);
 	r = fmadd(r, fmadd(-x, r, 1.0), r);
-	return fmadd(r, fmadd(-x, r, 1.0), r);
+	if (CRD_RCP_NEWTON >= 2) r = fmadd(r, fmadd(-x, r, 1.0), r);
+	return r;
 }
 __device__ __forceinline__ float reciprocal(float x)
 {
@@ -83,34 +87,49 @@ __device__ __forceinline__ float reciprocal(float x)
 	return fmadd(r, fmadd(-x, r, 1.0f), r);
 }
 
+// Third point-function variant besides CRD_MODEL_FHN / CRD_MODEL_GOLDBETER: Goldbeter with justDiffusion = 1, where the whole
+// reaction block, absorbing rows included, is skipped (src/GoldbeterModel_torus.cpp:668).  A compile-time variant: as a
+// run-time flag it cost every Goldbeter stage four conditional moves.
+constexpr int kModelDiffusionOnly = 2;
+inline int kernel_model(const SlabDesc &d) { return (d.model == CRD_MODEL_GOLDBETER && d.just_diffusion) ? kModelDiffusionOnly : d.model; }
+
+// rowp is the per-row parameter of the kinetics: FHN b(j) (src/FHNmodel_torus.cpp:623-632); Goldbeter v0 + v1 b(j), the
+// row-constant source term of src/GoldbeterModel_torus.cpp:715, formed once on the host (crd_create).
 template <typename Real, int MODEL>
-__device__ __forceinline__ void rhs_point(Real uC, Real uW, Real uE, Real uS, Real uN, Real v, Real cA, Real cX, Real cP, Real b,
-                                          Real ka4, bool zero, bool just_diffusion, Real &du, Real &dv)
+__device__ __forceinline__ void rhs_point(Real uC, Real uW, Real uE, Real uS, Real uN, Real v, Real cA, Real cX, Real cP, Real rowp,
+                                          Real ka4, bool zero, Real &du, Real &dv)
 {
 	// second differences as the reference writes them, (uE - 2 uC + uW), so that a constant field diffuses to exactly zero
 	const Real d2x = fmadd((Real)-2, uC, uE) + uW;
 	const Real d2y = fmadd((Real)-2, uC, uN) + uS;
 	const Real diff = fmadd(cA, uE - uW, fmadd(cX, d2x, cP * d2y));
-	if (MODEL == CRD_MODEL_FHN) {
+	if (MODEL == kModelDiffusionOnly) {
+		du = diff;
+		dv = (Real)0;
+		return;
+	} else if (MODEL == CRD_MODEL_FHN) {
 		const Real u3 = (uC * uC) * uC;
 		du = diff + (fmadd((Real)3.0, uC, -u3) - v);
-		dv = (Real)kFhnEpsilon * (uC + b);
+		dv = (Real)kFhnEpsilon * (uC + rowp);
 	} else {
-		// v2 = VM2 z^2 / (K2^2 + z^2), v3 = VM3 y^2 z^4 / ((KR^2 + y^2)(KA^4 + z^4)): one division for both Hill terms
-		// (a correctly rounded fp64 division costs 11 instructions on this ISA, the three extra multiplies 3)
+		// v2 = VM2 z^2 / (K2^2 + z^2), v3 = VM3 y^2 z^4 / ((KR^2 + y^2)(KA^4 + z^4)) enter both equations only through
+		// w = v2 - v3 (src/GoldbeterModel_torus.cpp:715-716: dZ = v0 + v1 b - w + kf Y - k Z, dY = w - kf Y): one quotient
+		// w = (VM2 z^2 dB - VM3 y^2 z^4 dA) / (dA dB) with dA = K2^2 + z^2, dB = (KR^2 + y^2)(KA^4 + z^4) -- 23 instructions for
+		// the kinetics against 27 with the two Hill terms formed separately (this kernel is bound by fp64 issue).
 		const Real z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
 		const Real dA = (Real)(kGbK2 * kGbK2) + z2, dB = ((Real)(kGbKr * kGbKr) + y2) * (ka4 + z4);
+#ifdef CRD_GB_TWO_QUOTIENTS  // A/B only
 		const Real rinv = reciprocal(dA * dB);
 		const Real v2 = ((Real)kGbVm2 * z2) * (dB * rinv);
 		const Real v3 = (((Real)kGbVm3 * y2) * z4) * (dA * rinv);
-		const Real src = fmadd((Real)kGbV1, b, (Real)kGbV0);  // v0 + v1 b
-		du = diff + fmadd(-(Real)kGbK, uC, ((src - v2) + v3) + (Real)kGbKf * v);
+		du = diff + fmadd(-(Real)kGbK, uC, ((rowp - v2) + v3) + (Real)kGbKf * v);
 		dv = (v2 - v3) - (Real)kGbKf * v;
-		if (just_diffusion) {  // src/GoldbeterModel_torus.cpp:668: the whole reaction block, absorbing rows included, is skipped
-			du = diff;
-			dv = (Real)0;
-			zero = false;
-		}
+#else
+		const Real n2 = ((Real)kGbVm2 * z2) * dB, n3 = (((Real)kGbVm3 * y2) * z4) * dA;
+		const Real w = (n2 - n3) * reciprocal(dA * dB);
+		dv = w - (Real)kGbKf * v;
+		du = diff + fmadd(-(Real)kGbK, uC, rowp - dv);  // rowp = v0 + v1 b
+#endif
 	}
 	if (zero) {
 		du = (Real)0;

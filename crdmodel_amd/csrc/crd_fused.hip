@@ -33,7 +33,13 @@ constexpr int kLanes = 64;
 constexpr int kValid = kLanes - 2 * kApron;  // 56 output columns per wavefront
 constexpr int kWavesPerBlock = 4;     // default; the launch may use 1 .. kMaxWavesPerBlock (tuning knob)
 constexpr int kMaxWavesPerBlock = 8;
-constexpr int kPrefetch = 4;                 // rows in flight per wavefront; equals the unroll factor so slots stay static
+// Rows in flight per wavefront (a divisor of the unroll factor, so slots stay static).  Tuning builds override per model.
+#ifndef CRD_PREFETCH_FHN
+#define CRD_PREFETCH_FHN 4
+#endif
+#ifndef CRD_PREFETCH_GB
+#define CRD_PREFETCH_GB 4
+#endif
 
 // Value held by lane-1 / lane+1 of this wavefront (the edge lane gets 0: it is apron garbage by design).  `old` = 0 with
 // bound_ctrl lets the DPP move write its destination without a tied input, i.e. without a copy in front of it.
@@ -78,6 +84,12 @@ __device__ __forceinline__ double uniform(double x)
 }
 __device__ __forceinline__ float uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
+#ifdef CRD_NT_LOADS  // A/B only: non-temporal row loads
+#define CRD_ROW_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define CRD_ROW_LOAD(p) (*(p))
+#endif
+
 template <typename Real>
 struct FusedArgs {
 	const Real *in_u, *in_v;  // y0, pointers to local row 0 (ghost rows at negative offsets)
@@ -112,6 +124,8 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	constexpr int APRON = EMBED ? kApron + 1 : kApron;
 	constexpr int VALID = kLanes - 2 * APRON;
 	constexpr int M = EMBED ? 8 : 4;  // register slots per pipeline array = unroll factor
+	constexpr int kPrefetch = (MODEL == CRD_MODEL_GOLDBETER) ? CRD_PREFETCH_GB : CRD_PREFETCH_FHN;
+	static_assert(M % kPrefetch == 0, "prefetch slots are addressed with the unrolled iteration index");
 	const int lane = threadIdx.x & (kLanes - 1);
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
 	// per-row table reads, the boundary-row tests) in scalar registers.
@@ -119,10 +133,22 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	// A block's wavefronts take adjacent strips of ONE chunk, blocks walk theta first.  The wavefronts of a block therefore
 	// run the same trip counts, and in lockstep (one barrier per pipeline iteration) their row reads reach the memory system
 	// together as one contiguous, overlapping run of a.sw x 448 B per row instead of drifting apart.
-	const int blk = a.remap ? xcd_remap((int)blockIdx.x, a.nblocks) : (int)blockIdx.x;
+	const int blk = a.remap == 1 ? xcd_remap((int)blockIdx.x, a.nblocks) : (int)blockIdx.x;
 	const int nsb = (a.nstrips + a.sw - 1) / a.sw;
-	const int strip = __builtin_amdgcn_readfirstlane((blk % nsb) * a.sw + (int)(threadIdx.x >> 6));
-	const int chunk = __builtin_amdgcn_readfirstlane(blk / nsb);
+	int sblk = blk % nsb, cblk = blk / nsb;
+	if (a.remap == 2) {
+		// Chunks in groups of eight, one chunk per XCD: block ids 8k + x of a group (workgroups are dealt round-robin over the
+		// XCDs, and a group holds a multiple of eight blocks) cover strip block k of the group's chunk x, so theta-neighbouring
+		// blocks share an L2 and fetch their common apron columns from beyond it once.  The last, partial group keeps chunk order.
+		const int group = kNumXcd * nsb, g = blk / group;
+		if ((g + 1) * kNumXcd <= a.nchunks) {
+			const int r = blk - g * group;
+			sblk = r / kNumXcd;
+			cblk = g * kNumXcd + r % kNumXcd;
+		}
+	}
+	const int strip = __builtin_amdgcn_readfirstlane(sblk * a.sw + (int)(threadIdx.x >> 6));
+	const int chunk = __builtin_amdgcn_readfirstlane(cblk);
 	if (strip >= a.nstrips || chunk >= a.nchunks) return;  // (a barrier waits for the surviving wavefronts of the workgroup only)
 	const int item = chunk * a.nstrips + strip;
 	const int nx = s.nx;
@@ -142,7 +168,9 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	const int jlast = j1 + APRON - 1;  // last row the pipeline consumes
 
 	const Real cA = s.cA[x], cP = s.cP[x], cX = s.cX, ka4 = s.ka4;
-	const bool jd = s.just_diffusion != 0;
+	// b(j) is read-only for the whole launch and its index is uniform: through the constant address space the reads become
+	// scalar-cache loads into SGPRs (s_load_dwordx2), no vector registers and no vector-memory instruction
+	const __attribute__((address_space(4))) Real *const brow = (const __attribute__((address_space(4))) Real *)(s.brow);
 
 	// Row base pointers are scalar; a single slab wraps rows outside [0, nyl).
 	auto row_base = [&](int j) -> ptrdiff_t {
@@ -179,9 +207,9 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	for (int k = 0; k < kPrefetch; k++) {
 		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
 		const ptrdiff_t rb = row_base(jr);
-		pu[k] = a.in_u[rb + x];
-		pv[k] = a.in_v[rb + x];
-		pb[k] = s.brow[jr];
+		pu[k] = CRD_ROW_LOAD(a.in_u + rb + x);
+		pv[k] = CRD_ROW_LOAD(a.in_v + rb + x);
+		pb[k] = brow[jr];
 	}
 #pragma unroll
 	for (int k = 0; k < M; k++) bq[k] = (Real)0;
@@ -204,16 +232,16 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		{
 			const int pn = (p + kPrefetch < jlast) ? p + kPrefetch : jlast;  // the tail re-reads a valid row instead of running past the plane
 			const ptrdiff_t rb = row_base(pn);
-			pu[P] = a.in_u[rb + x];
-			pv[P] = a.in_v[rb + x];
-			pb[P] = s.brow[pn];
+			pu[P] = CRD_ROW_LOAD(a.in_u + rb + x);
+			pv[P] = CRD_ROW_LOAD(a.in_v + rb + x);
+			pb[P] = brow[pn];
 		}
 		Real du, dv;
 		// ---- stage 1, centre row p-1: y0 rows p-2, p-1, p -----------------------------------------------------
 		if (!GUARDED || m >= 2) {
 			const int c = p - 1;
 			rhs_point<Real, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
-			                       ABSORB && a.absorb[0] && boundary_row(c), jd, du, dv);
+			                       ABSORB && a.absorb[0] && boundary_row(c), du, dv);
 			U1[S1] = fmadd(a.h2, du, u0[S1]);
 			V1[S1 & 1] = fmadd(a.h2, dv, v0[S1]);
 			aU[S1] = fmadd(a.h6, du, u0[S1]);
@@ -223,7 +251,7 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		if (!GUARDED || m >= 4) {
 			const int c = p - 2;
 			rhs_point<Real, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[S2 & 1], cA, cX, cP, bq[S2], ka4,
-			                       ABSORB && a.absorb[1] && boundary_row(c), jd, du, dv);
+			                       ABSORB && a.absorb[1] && boundary_row(c), du, dv);
 			U2[S2] = fmadd(a.h2, du, u0[S2]);
 			V2[S2 & 1] = fmadd(a.h2, dv, v0[S2]);
 			aU[S2] = fmadd(a.h3, du, aU[S2]);
@@ -233,7 +261,7 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		if (!GUARDED || m >= 6) {
 			const int c = p - 3;
 			rhs_point<Real, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[S3 & 1], cA, cX, cP, bq[S3], ka4,
-			                       ABSORB && a.absorb[2] && boundary_row(c), jd, du, dv);
+			                       ABSORB && a.absorb[2] && boundary_row(c), du, dv);
 			U3[S3] = fmadd(a.h1, du, u0[S3]);
 			V3[S3 & 1] = fmadd(a.h1, dv, v0[S3]);
 			aU[S3] = fmadd(a.h3, du, aU[S3]);
@@ -243,7 +271,7 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		if (!GUARDED || m >= 8) {
 			const int c = p - 4;
 			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
-			                       ABSORB && a.absorb[3] && boundary_row(c), jd, du, dv);
+			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);
 			const Real nu = fmadd(a.h6, du, aU[S4]), nv = fmadd(a.h6, dv, aV[S4]);
 			if ((EMBED ? (c >= j0 && c < j1) : c < j1) && lane_stores) {  // without the fifth stage c >= j0 holds from iteration 8 on
 				const ptrdiff_t o = (ptrdiff_t)c * nx + out_col;
@@ -261,7 +289,7 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		if (EMBED && (!GUARDED || m >= 10)) {
 			const int c = p - 5;
 			rhs_point<Real, MODEL>(U4[S5], from_lane_below(U4[S5]), from_lane_above(U4[S5]), U4[S6], U4[S4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
-			                       ABSORB && a.absorb[3] && boundary_row(c), jd, du, dv);  // k5 is evaluated at t + dt, like k4
+			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);  // k5 is evaluated at t + dt, like k4
 			if (lane_stores) {  // rows j0 .. j1-1 exactly: stage 5 starts at iteration 10 (row j0) and the loop ends at row j1-1
 				const Real au = u0[S5] < (Real)0 ? -u0[S5] : u0[S5], av = v0[S5] < (Real)0 ? -v0[S5] : v0[S5];
 				const Real eu = a.h6 * (K4U[S5 & 1] - du) / fmadd(a.rtol, au, a.atol);
@@ -322,11 +350,12 @@ __global__ void __launch_bounds__(256) crd_sum_partials_kernel(const double *__r
 
 // Tuning knobs (tools/tune_fused.py, tools/ring_ab.py flip them between launches of one process).  They are honoured only
 // when CRD_TUNING is set in the environment at the first launch; a production process never reads them.
-const char *tuning_knob(const char *name)
+bool tuning_enabled()
 {
 	static const bool enabled = std::getenv("CRD_TUNING") != nullptr;
-	return enabled ? std::getenv(name) : nullptr;
+	return enabled;
 }
+const char *tuning_knob(const char *name) { return tuning_enabled() ? std::getenv(name) : nullptr; }
 
 // Rows per work item.  Every item pays 8 apron rows, which argues for long chunks; but the wavefronts of a launch run in
 // "rounds" of (resident wavefront slots) items, a partly filled last round idles most of the chip, unequal wavefront
@@ -335,8 +364,10 @@ const char *tuning_knob(const char *name)
 // chunk 32 0.434 ms, 24 0.451, 50 0.463, 60 0.477, 75 0.494, 128 0.51, 1024 0.62 -- many short items win.  So: 32 rows,
 // halved while the launch would not fill every slot once (an 8192 x 1024 slab, one rank's share of 8 GPUs, sweeps in
 // 58.4 us with 32-row chunks and 60.5 with 16; the edge-band launches of a multi-slab step end up with 8-row chunks).
+// `one_round` (a launch-plan choice, see FusedPlan): a launch that needs more than one round of resident blocks but would
+// fit into one with chunks of up to 96 rows gets those longer chunks -- no tail round on an almost idle chip.
 template <typename Real, int MODEL>
-int fused_chunk_rows(int nstrips, int rows)
+int fused_chunk_rows(int nstrips, int rows, bool one_round)
 {
 	static int slots = 0;  // resident wavefronts of this kernel on the current device
 	if (slots == 0) {
@@ -351,12 +382,29 @@ int fused_chunk_rows(int nstrips, int rows)
 	}
 	int chunk = 32;
 	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
+	if (const char *e = tuning_knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
+	if (one_round) {
+		const long strip_blocks = (nstrips + kWavesPerBlock - 1) / kWavesPerBlock, fit = (slots / kWavesPerBlock) / strip_blocks;
+		const long need = fit >= 1 ? (rows + fit - 1) / fit : 0;
+		if (need > chunk && need <= 96) chunk = (int)need;
+	}
 	if (const char *e = tuning_knob("CRD_FUSED_CHUNK")) {  // tuning knob
 		const int v = std::atoi(e);
 		if (v >= 1) chunk = v;
 	}
 	return chunk < rows ? chunk : rows;
 }
+
+// Launch-plan candidates the autotuner times: (chunks stretched to one round?, block -> item mapping).  Mapping 0 walks the
+// items theta-first in dispatch order; 1 gives each XCD one contiguous run of items (a contiguous band of the slab: phi- and
+// theta-neighbouring items then share an L2); 2 deals chunks round-robin to the XCDs in groups of eight.  Which one is
+// fastest depends on the grid shape AND on the device: on 8192^2 fp64 mapping 1 measured -6.3 %, -0.7 % and +1.7 % against
+// mapping 0 on three MI355X of the same pool, one-round chunks -10 % (4096 x 1024) to +2 % (16384 x 2048 fp32) -- hence
+// measured at run time, on the device and the shape at hand.  Every candidate computes bit-identical results.
+struct PlanCandidate {
+	int one_round, remap;
+};
+constexpr PlanCandidate kPlanCandidates[] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {1, 1}};
 
 template <typename Real, int MODEL>
 hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, int js, int ny,
@@ -387,10 +435,6 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
 	a.row_begin2 = row_begin2;
 	a.row_end2 = row_end2;
-	a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2);
-	a.nchunks1 = (rows + a.chunk - 1) / a.chunk;
-	a.nchunks = a.nchunks1 + (rows2 + a.chunk - 1) / a.chunk;
-	a.nitems = a.nstrips * a.nchunks;
 	// Four adjacent strips per block marching in lockstep: 0.417 ms on 8192^2 fp64 against 0.441 without the barriers and
 	// 0.4205 with one barrier per four iterations (tools/tune_fused.py, interleaved in one process; fp32 0.219 vs 0.232,
 	// Goldbeter -- instruction-bound -- unchanged); 2 or 8 strips per block lose half of the gain, 3 / 5 / 6 more.
@@ -402,25 +446,83 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	if (const char *e = tuning_knob("CRD_FUSED_LOCKSTEP")) lockstep = std::atoi(e) != 0;
 	a.sw = sw;
 	a.lockstep = lockstep;
-	const int nblocks = ((a.nstrips + sw - 1) / sw) * a.nchunks;
-	a.nblocks = nblocks;
-	a.remap = tuning_knob("CRD_FUSED_REMAP") ? 1 : 0;  // tuning knob: XCD-contiguous item runs (helps long chunks, hurts 32-row ones)
 	a.err_partials = c.err_partials;
 	a.rtol = (Real)c.rtol;
 	a.atol = (Real)c.atol;
-	const bool absorb = c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3];
+	// the reaction block of a diffusion-only run is skipped, absorbing rows included (src/GoldbeterModel_torus.cpp:668)
+	constexpr bool kCanAbsorb = MODEL != kModelDiffusionOnly;
+	const bool absorb = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3]);
 	const dim3 block(kLanes * sw);
-	if (c.embed) {
-		if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
-		if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, true, true><<<nblocks, block, 0, st>>>(s, a);
-		else crd_rk4_fused_step_kernel<Real, MODEL, false, true><<<nblocks, block, 0, st>>>(s, a);
-		crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
-	} else if (absorb) {
-		crd_rk4_fused_step_kernel<Real, MODEL, true, false><<<nblocks, block, 0, st>>>(s, a);
-	} else {
-		crd_rk4_fused_step_kernel<Real, MODEL, false, false><<<nblocks, block, 0, st>>>(s, a);
+
+	auto configure = [&](int one_round, int remap) {
+		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round != 0);
+		a.nchunks1 = (rows + a.chunk - 1) / a.chunk;
+		a.nchunks = a.nchunks1 + (rows2 + a.chunk - 1) / a.chunk;
+		a.nitems = a.nstrips * a.nchunks;
+		a.nblocks = ((a.nstrips + sw - 1) / sw) * a.nchunks;
+		a.remap = remap;
+		if (const char *e = tuning_knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);  // tuning knob
+	};
+	auto fire = [&]() -> hipError_t {
+		if (c.embed) {
+			if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
+			if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, true><<<a.nblocks, block, 0, st>>>(s, a);
+			else crd_rk4_fused_step_kernel<Real, MODEL, false, true><<<a.nblocks, block, 0, st>>>(s, a);
+			crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
+		} else if (absorb) {
+			crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, false><<<a.nblocks, block, 0, st>>>(s, a);
+		} else {
+			crd_rk4_fused_step_kernel<Real, MODEL, false, false><<<a.nblocks, block, 0, st>>>(s, a);
+		}
+		return launch_status();
+	};
+
+	// Launch plan: measured once per context on the first full-size launch (a launch reads one plane set and writes another, so
+	// repeating it is harmless: every candidate writes the same values), then reused for every launch of similar height.
+	FusedPlan *plan = c.plan;
+	const bool plannable = plan && rows2 == 0 && (long)rows * d.nx >= (1L << 20) && !tuning_enabled();  // (under CRD_TUNING the knobs decide)
+	if (plannable && !plan->tuned && plan->autotune) {
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		hipError_t err = hipEventCreate(&e0);
+		if (err == hipSuccess) err = hipEventCreate(&e1);
+		float best = 0.f, base = 0.f;
+		int best_k = 0, reps = 3;
+		for (int k = 0; err == hipSuccess && k < (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]); k++) {
+			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap);
+			if (kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, false)) continue;  // same as the 32-row plan
+			float ms = 0.f;
+			for (int pass = 0; pass < 2 && err == hipSuccess; pass++) {
+				err = fire();  // warm-up of this variant
+				if (err == hipSuccess) err = hipEventRecord(e0, st);
+				for (int r = 0; err == hipSuccess && r < reps; r++) err = fire();
+				if (err == hipSuccess) err = hipEventRecord(e1, st);
+				if (err == hipSuccess) err = hipEventSynchronize(e1);
+				if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+				if (k > 0 || reps > 3 || ms >= 1.0f || ms <= 0.f) break;
+				reps = (int)(3.0f / ms) + 1 < 30 ? (int)(3.0f / ms) + 1 : 30;  // short launches: time about a millisecond's worth, then again
+			}
+			if (err != hipSuccess) break;
+			ms *= 3.0f / (float)reps;  // per three launches, whatever the repetition count
+			if (k == 0) base = best = ms;
+			else if (ms < best) {
+				best = ms;
+				best_k = k;
+			}
+		}
+		if (e0) (void)hipEventDestroy(e0);
+		if (e1) (void)hipEventDestroy(e1);
+		if (err != hipSuccess) return err;
+		if (best > 0.99f * base) best_k = 0;  // a candidate has to beat the plain plan by more than timing noise
+		plan->tuned = 1;
+		plan->one_round = kPlanCandidates[best_k].one_round;
+		plan->remap = kPlanCandidates[best_k].remap;
+		plan->rows = rows;
+		plan->ms_default = base / 3.f;
+		plan->ms_best = best / 3.f;
 	}
-	return launch_status();
+	const bool use_plan = plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows;
+	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0);
+	return fire();
 }
 
 }  // namespace
@@ -440,11 +542,16 @@ hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &
                              hipStream_t s)
 {
 	static_assert(kApron == kStepHalo && kGhost >= kStepHalo, "the planes carry at least the ghost rows one fused step consumes");
-	if (precision == CRD_PRECISION_F64)
-		return d.model == CRD_MODEL_FHN ? launch_fused_t<double, CRD_MODEL_FHN>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s)
-		                                : launch_fused_t<double, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s);
-	return d.model == CRD_MODEL_FHN ? launch_fused_t<float, CRD_MODEL_FHN>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s)
-	                                : launch_fused_t<float, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s);
+	const int model = kernel_model(d);
+#define CRD_FUSED_DISPATCH(REAL)                                                                                             \
+	switch (model) {                                                                                                         \
+	case CRD_MODEL_FHN: return launch_fused_t<REAL, CRD_MODEL_FHN>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s);          \
+	case CRD_MODEL_GOLDBETER: return launch_fused_t<REAL, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s); \
+	default: return launch_fused_t<REAL, kModelDiffusionOnly>(d, c, row_begin, row_end, row_begin2, row_end2, d.js, d.ny, s);              \
+	}
+	if (precision == CRD_PRECISION_F64) CRD_FUSED_DISPATCH(double)
+	CRD_FUSED_DISPATCH(float)
+#undef CRD_FUSED_DISPATCH
 }
 
 }  // namespace crd

@@ -55,6 +55,16 @@ const char *stage_kernel_name(int precision, int model);
 
 // Whole RK4 step in one launch (all four stages on chip); reads y0 with kGhost ghost rows, writes yout rows
 // [row_begin, row_end) and, if non-empty, [row_begin2, row_end2).  absorb[k] = t_stage_k < tBoundary for the four stages.
+// How the one-launch step cuts a slab into work items and deals them to the XCDs (crd_fused.hip: kPlanCandidates), measured
+// on the first full-size launch of a context when autotune is set.  Every plan computes bit-identical results.
+struct FusedPlan {
+	int autotune = 1;
+	int tuned = 0;
+	int one_round = 0, remap = 0;
+	int rows = 0;                          // height of the launch the plan was measured on
+	float ms_default = 0.f, ms_best = 0.f;  // measured launch times of the plain plan and of the chosen one
+};
+
 struct FusedCall {
 	double dt;
 	int absorb[4];
@@ -66,6 +76,7 @@ struct FusedCall {
 	double *err_partials = nullptr;  // device scratch, err_capacity doubles (>= fused_max_items)
 	int err_capacity = 0;
 	double *err_sum = nullptr;       // device: the sum, written by a follow-up reduction on the same stream
+	FusedPlan *plan = nullptr;       // launch plan of the context (nullptr: plain plan)
 };
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s);

@@ -95,7 +95,7 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, S
 		const bool zero = a.absorb && ((s.has_row0 && j == 0) || (s.has_rowN && j == s.nyl - 1));
 		Real du, dv;
 		rhs_point<Real, MODEL>(uC[r], tile[tr][tx], tile[tr][tx + 2], tile[tr - 1][tx + 1], tile[tr + 1][tx + 1], vC[r], cA, s.cX, cP,
-		                       s.brow[j], s.ka4, zero, s.just_diffusion != 0, du, dv);
+		                       s.brow[j], s.ka4, zero, du, dv);
 		const size_t o = (size_t)j * nx + i;
 		if (STAGE == 0) {
 			a.out_u[o] = du;
@@ -172,7 +172,7 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, con
 		const bool zero = absorb && ((s.has_row0 && j == 0) || (s.has_rowN && j == nyl - 1));
 		P k;
 		rhs_point<Real, MODEL>(own[r].x, tile[tr][tx], tile[tr][tx + 2], tile[tr - 1][tx + 1], tile[tr + 1][tx + 1], own[r].y, cA, s.cX, cP,
-		                       s.brow[j], s.ka4, zero, s.just_diffusion != 0, k.x, k.y);
+		                       s.brow[j], s.ka4, zero, k.x, k.y);
 		ydot[(size_t)j * nx + i] = k;
 	}
 }
@@ -284,11 +284,16 @@ hipError_t launch_rhs_aos_t(const SlabDesc &d, int absorb, const void *y, void *
 
 hipError_t launch_stage(int precision, const SlabDesc &d, const StageCall &c, int row_begin, int row_end, hipStream_t s)
 {
-	if (precision == CRD_PRECISION_F64)
-		return d.model == CRD_MODEL_FHN ? launch_stage_t<double, CRD_MODEL_FHN>(d, c, row_begin, row_end, s)
-		                                : launch_stage_t<double, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, s);
-	return d.model == CRD_MODEL_FHN ? launch_stage_t<float, CRD_MODEL_FHN>(d, c, row_begin, row_end, s)
-	                                : launch_stage_t<float, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, s);
+	const int model = kernel_model(d);
+#define CRD_STAGE_DISPATCH(REAL)                                                                            \
+	switch (model) {                                                                                        \
+	case CRD_MODEL_FHN: return launch_stage_t<REAL, CRD_MODEL_FHN>(d, c, row_begin, row_end, s);            \
+	case CRD_MODEL_GOLDBETER: return launch_stage_t<REAL, CRD_MODEL_GOLDBETER>(d, c, row_begin, row_end, s); \
+	default: return launch_stage_t<REAL, kModelDiffusionOnly>(d, c, row_begin, row_end, s);                 \
+	}
+	if (precision == CRD_PRECISION_F64) CRD_STAGE_DISPATCH(double)
+	CRD_STAGE_DISPATCH(float)
+#undef CRD_STAGE_DISPATCH
 }
 
 const char *stage_kernel_name(int, int) { return "crd_rk4_stage_kernel"; }
@@ -296,11 +301,16 @@ const char *stage_kernel_name(int, int) { return "crd_rk4_stage_kernel"; }
 hipError_t launch_rhs_aos(int precision, const SlabDesc &d, int absorb, const void *y, void *ydot, const void *ghost_lo, const void *ghost_hi,
                           int row_begin, int row_end, hipStream_t s)
 {
-	if (precision == CRD_PRECISION_F64)
-		return d.model == CRD_MODEL_FHN ? launch_rhs_aos_t<double, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s)
-		                                : launch_rhs_aos_t<double, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s);
-	return d.model == CRD_MODEL_FHN ? launch_rhs_aos_t<float, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s)
-	                                : launch_rhs_aos_t<float, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s);
+	const int model = kernel_model(d);
+#define CRD_AOS_DISPATCH(REAL)                                                                                                               \
+	switch (model) {                                                                                                                         \
+	case CRD_MODEL_FHN: return launch_rhs_aos_t<REAL, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s);         \
+	case CRD_MODEL_GOLDBETER: return launch_rhs_aos_t<REAL, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s); \
+	default: return launch_rhs_aos_t<REAL, kModelDiffusionOnly>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s);              \
+	}
+	if (precision == CRD_PRECISION_F64) CRD_AOS_DISPATCH(double)
+	CRD_AOS_DISPATCH(float)
+#undef CRD_AOS_DISPATCH
 }
 
 hipError_t launch_aos_to_planes(int precision, int src_is_f64, const void *aos, Planes dst, int nx, int nyl, hipStream_t s)

@@ -201,6 +201,7 @@ FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int ds
 	for (int k = 0; k < 4; k++) call.absorb[k] = absorbing(c, t + cs[k] * dt) ? 1 : 0;
 	call.y0 = c->planes(src);
 	call.yout = c->planes(dst);
+	call.plan = const_cast<FusedPlan *>(&c->plan);
 	return call;
 }
 
@@ -383,6 +384,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			if ((rc = set_device(c))) break;
 			FusedCall call = make_fused_call(c, t, hh, cur, dst);
 			call.embed = 1;
+			call.plan = &c->plan_embed;
 			call.rtol = o.rtol;
 			call.atol = o.atol;
 			call.err_partials = c->err_partials;

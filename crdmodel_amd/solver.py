@@ -241,6 +241,15 @@ class Slab:
     def dominant_kernel(self):
         return lib().crd_dominant_kernel_name(self._h).decode()
 
+    def set_autotune(self, on):
+        self._check(lib().crd_set_autotune(self._h, 1 if on else 0), "crd_set_autotune")
+
+    def launch_plan(self):
+        """The fused step kernel's launch plan as a dict (crd_launch_plan)."""
+        lp = capi.LaunchPlan()
+        self._check(lib().crd_get_launch_plan(self._h, C.byref(lp)), "crd_get_launch_plan")
+        return {f: getattr(lp, f) for f, _ in lp._fields_ if f != "reserved"}
+
     def max_abs(self):
         v = C.c_double()
         self._check(lib().crd_state_max_abs(self._h, C.byref(v)), "crd_state_max_abs")

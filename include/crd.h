@@ -280,6 +280,23 @@ int crd_dominant_kernel_rows(const crd_ctx *ctx, int64_t *rows);
 /* Name of the dominant kernel as it appears in a rocprofv3 kernel trace (static string). */
 const char *crd_dominant_kernel_name(const crd_ctx *ctx);
 
+/* Launch plan of the one-launch step kernel.  How a slab is cut into work items (32-row chunks, or chunks stretched so that
+ * every workgroup is resident at once) and how the items are dealt to the 8 XCDs is measured on the device at hand, on the
+ * context's first full-size step (a handful of extra launches of that step; every plan computes bit-identical results), unless
+ * autotuning is off (crd_set_autotune(ctx, 0) or CRD_AUTOTUNE=0 in the environment: always the plain plan).  No reference
+ * counterpart: a property of this implementation. */
+typedef struct crd_launch_plan {
+	int32_t autotune;     /* measuring enabled */
+	int32_t tuned;        /* a measurement has been made */
+	int32_t one_round;    /* chunks stretched so that all workgroups are resident at once */
+	int32_t xcd_mapping;  /* 0 theta-first dispatch order, 1 one contiguous band of the slab per XCD, 2 chunks dealt to XCDs in groups of 8 */
+	int32_t rows;         /* height of the launch it was measured on */
+	int32_t reserved;
+	double ms_default, ms_chosen; /* measured launch times: plain plan, chosen plan */
+} crd_launch_plan;
+int crd_set_autotune(crd_ctx *ctx, int on);
+int crd_get_launch_plan(const crd_ctx *ctx, crd_launch_plan *out);
+
 /* max |var0| over the slab (blow-up guard; synchronises). */
 int crd_state_max_abs(crd_ctx *ctx, double *out);
 

@@ -16,7 +16,8 @@ variants = [v for v in os.environ.get("TUNE_VARIANTS", "chunk=0;chunk=75;chunk=6
 model = os.environ.get("TUNE_MODEL", "fhn")
 prec = os.environ.get("TUNE_PRECISION", "f64")
 
-p = crd.make_params(model, "torus", n, 80.0, 20.0, 0.12, 1.25 if model == "fhn" else 0.4, ny=n, precision=prec)
+ny = int(os.environ.get("TUNE_NY", str(n)))
+p = crd.make_params(model, "torus", n, 80.0, 20.0, 0.12, 1.25 if model == "fhn" else 0.4, ny=ny, precision=prec)
 dt = 0.8 * crd.stable_dt(p)
 cfg = crd.run_config(p)
 slab = crd.Slab(p)
@@ -27,7 +28,7 @@ slab.step_rk4(0.0, dt, 50)
 res = {v: [] for v in variants}
 for r in range(rounds):
     for v in variants:
-        for k in ("CRD_FUSED_CHUNK", "CRD_FUSED_REMAP", "CRD_FUSED_STRIPS", "CRD_FUSED_LOCKSTEP"):
+        for k in ("CRD_FUSED_CHUNK", "CRD_FUSED_REMAP", "CRD_FUSED_STRIPS", "CRD_FUSED_LOCKSTEP", "CRD_FUSED_ONEROUND"):
             os.environ.pop(k, None)
         for kv in v.split(","):
             key, val = kv.split("=")
@@ -37,10 +38,12 @@ for r in range(rounds):
                 os.environ["CRD_FUSED_STRIPS"] = val
             if key == "lockstep":
                 os.environ["CRD_FUSED_LOCKSTEP"] = val
-            if key == "remap" and val == "1":
-                os.environ["CRD_FUSED_REMAP"] = "1"
+            if key == "oneround":
+                os.environ["CRD_FUSED_ONEROUND"] = val
+            if key == "remap" and val != "0":
+                os.environ["CRD_FUSED_REMAP"] = val
         ms, kms, _ = slab.step_rk4_timed(0.0, dt, steps)
         res[v].append(ms / steps)
 for v in variants:
     t = res[v]
-    print("%-28s median %.4f ms  min %.4f  max %.4f  -> %.3e pt-steps/s" % (v, statistics.median(t), min(t), max(t), n * n / (statistics.median(t) * 1e-3)))
+    print("%-28s median %.4f ms  min %.4f  max %.4f  -> %.3e pt-steps/s" % (v, statistics.median(t), min(t), max(t), n * ny / (statistics.median(t) * 1e-3)))
