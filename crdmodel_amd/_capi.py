@@ -57,14 +57,15 @@ class AdaptiveOptions(C.Structure):
     """crd_adaptive_options"""
 
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("h0", C.c_double), ("safety", C.c_double), ("bias", C.c_double),
-                ("growth", C.c_double), ("shrink", C.c_double), ("max_steps", C.c_int64), ("h_max", C.c_double)]
+                ("growth", C.c_double), ("shrink", C.c_double), ("max_steps", C.c_int64), ("h_max", C.c_double), ("dense_output", C.c_int32),
+                ("reserved", C.c_int32)]
 
 
 class AdaptiveStats(C.Structure):
     """crd_adaptive_stats"""
 
     _fields_ = [("accepted", C.c_int64), ("rejected", C.c_int64), ("h_last", C.c_double), ("h_next", C.c_double), ("h_min", C.c_double),
-                ("h_max", C.c_double), ("err_last", C.c_double), ("t", C.c_double)]
+                ("h_max", C.c_double), ("err_last", C.c_double), ("t", C.c_double), ("t_internal", C.c_double)]
 
 
 class RunConfig(C.Structure):
@@ -104,6 +105,9 @@ _SIGNATURES = {
     "crd_writer_open": (C.c_int, [C.POINTER(RunConfig), C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
     "crd_writer_write_row": (C.c_int, [_vp, _vp]),
     "crd_writer_close": (C.c_int, [_vp]),
+    "crd_npy_writer_open": (C.c_int, [C.POINTER(RunConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "crd_npy_writer_append": (C.c_int, [_vp, _vp]),
+    "crd_npy_writer_close": (C.c_int, [_vp]),
     "crd_device_count": (C.c_int, []),
     "crd_create": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "crd_destroy": (None, [_vp]),
@@ -186,7 +190,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.crd_abi_version() != 1:
+        if L.crd_abi_version() != 2:
             raise ImportError("libcrd.so ABI version mismatch")
         _lib = L
     return _lib

@@ -150,7 +150,7 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_interior, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreate(&c->ev_t0));
 	CREATE_TRY(hipEventCreate(&c->ev_t1));
-	for (int k = 0; k < crd_ctx::NPLANES; k++)
+	for (int k = 0; k < crd_ctx::OUT; k++)  // (the OUT plane is allocated by the first dense-output call)
 		for (int f = 0; f < 2; f++) {
 			CREATE_TRY(hipMalloc(&c->plane[k][f], c->plane_bytes));
 			CREATE_TRY(hipMemsetAsync(c->plane[k][f], 0, c->plane_bytes, c->compute));
@@ -357,6 +357,7 @@ int crd_state_upload(crd_ctx *c, const void *y, int host_is_f64)
 	if (int rc = set_device(c)) return rc;
 	const size_t bytes = 2 * (size_t)c->nx * (size_t)c->nyl * (host_is_f64 ? 8 : 4);
 	if (int rc = ensure_staging(c, 2 * (size_t)c->nx * (size_t)c->nyl * 8)) return rc;
+	c->dense.pending = false;  // a new state: nothing to resume
 	HIP_TRY(c, hipMemcpyAsync(c->stage_in, y, bytes, hipMemcpyHostToDevice, c->compute));
 	HIP_TRY(c, launch_aos_to_planes(c->p.precision, host_is_f64, c->stage_in, c->planes(crd_ctx::Y), c->nx, c->nyl, c->compute));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));

@@ -66,7 +66,8 @@ struct crd_ctx {
 	size_t plane_bytes = 0;
 
 	// State planes: Y (current), SA / SB (stage ping-pong), ACC; [k][0] = var0, [k][1] = var1.
-	enum { Y = 0, SA = 1, SB = 2, ACC = 3, NPLANES = 4 };
+	// OUT exists only in contexts that have produced dense output (lazy): the third state plane of crd_integrate_adaptive.
+	enum { Y = 0, SA = 1, SB = 2, ACC = 3, OUT = 4, NPLANES = 5 };
 	void *plane[NPLANES][2] = {};
 	void *cA = nullptr, *cP = nullptr, *brow = nullptr;
 	void *stage_in = nullptr, *stage_out = nullptr;  // AoS staging for the *_host entry points (lazy)
@@ -87,6 +88,13 @@ struct crd_ctx {
 	std::vector<hipEvent_t> ev_k;  // per-launch timing events
 	hipStream_t down = nullptr;    // device-to-host stream of the pipelined crd_rhs_host (lazy)
 	std::vector<hipEvent_t> ev_band;  // its per-band events (lazy)
+
+	// Dense output of the adaptive integrator (ARK_NORMAL): after a call that overshot tout, plane Y holds the interpolant at
+	// t_out, SA the integrator's own state y_{n+1} at t_np1, OUT y_n at t_n, SB / ACC f(t_n, y_n) / f(t_{n+1}, y_{n+1}).
+	struct {
+		bool pending = false;
+		double t_out = 0.0, t_n = 0.0, t_np1 = 0.0;
+	} dense;
 
 	crd::SlabDesc desc{};
 	int stepper = CRD_STEPPER_AUTO;

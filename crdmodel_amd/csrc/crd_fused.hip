@@ -19,6 +19,7 @@
 
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 #include "crd_device.h"
 
@@ -39,6 +40,12 @@ constexpr int kMaxWavesPerBlock = 8;
 #endif
 #ifndef CRD_PREFETCH_GB
 #define CRD_PREFETCH_GB 4
+#endif
+#ifndef CRD_EMBED_SLOTS
+#define CRD_EMBED_SLOTS 6
+#endif
+#ifndef CRD_PREFETCH_EMBED
+#define CRD_PREFETCH_EMBED 3
 #endif
 
 // Value held by lane-1 / lane+1 of this wavefront (the edge lane gets 0: it is apron garbage by design).  `old` = 0 with
@@ -75,6 +82,13 @@ __device__ __forceinline__ float from_lane_above<float>(float x)
 {
 	const int v = __float_as_int(x);
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true));
+}
+
+// f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a compile-time unrolled loop.
+template <typename F, int... Is>
+__device__ __forceinline__ void for_sequence(F &&f, std::integer_sequence<int, Is...>)
+{
+	(f(std::integral_constant<int, Is>{}), ...);
 }
 
 // A value known to be identical in every lane, moved to scalar registers.
@@ -117,14 +131,18 @@ struct FusedArgs {
 //   sum_i (err_i / (rtol |y_n,i| + atol))^2
 // over this work item's outputs is written to err_partials[item] (ARKode's WRMS norm, src/FHNmodel_torus.cpp:365, is
 // sqrt(sum / N)).  The propagated solution is classical RK4 either way.  The pipeline is then five rows / columns deep
-// (apron 5, 54 valid lanes) and uses 8 register slots per array, the loop being unrolled 8 times.
+// (apron 5, 54 valid lanes) and uses 6 register slots per array, the loop being unrolled 6 times (165 VGPRs in fp64, three
+// wavefronts per SIMD; with 8 slots it was 203 and two).
 template <typename Real, int MODEL, bool ABSORB, bool EMBED>
 __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
 	constexpr int APRON = EMBED ? kApron + 1 : kApron;
 	constexpr int VALID = kLanes - 2 * APRON;
-	constexpr int M = EMBED ? 8 : 4;  // register slots per pipeline array = unroll factor
-	constexpr int kPrefetch = (MODEL == CRD_MODEL_GOLDBETER) ? CRD_PREFETCH_GB : CRD_PREFETCH_FHN;
+	// Register slots per pipeline array = unroll factor: the rows alive at once (4, or 6 with the fifth stage) -- even, because
+	// the two-deep arrays below are addressed with the slot's parity.
+	constexpr int M = EMBED ? CRD_EMBED_SLOTS : 4;
+	static_assert(M % 2 == 0 && M >= (EMBED ? 6 : 4), "slot count");
+	constexpr int kPrefetch = EMBED ? ((MODEL == CRD_MODEL_GOLDBETER && sizeof(Real) == 8) ? 2 : CRD_PREFETCH_EMBED) : (MODEL == CRD_MODEL_GOLDBETER) ? CRD_PREFETCH_GB : CRD_PREFETCH_FHN;
 	static_assert(M % kPrefetch == 0, "prefetch slots are addressed with the unrolled iteration index");
 	const int lane = threadIdx.x & (kLanes - 1);
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
@@ -301,28 +319,20 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	using std::integral_constant;
 	// guarded prologue: up to the first multiple of M at or beyond 2 * APRON, so the steady-state loop starts at slot 0
 	constexpr int PRO = ((2 * APRON + M - 1) / M) * M;
-	auto prologue = [&](auto... ks) { ((decltype(ks)::value < niter ? iteration(decltype(ks)::value, integral_constant<int, decltype(ks)::value % M>{}, std::true_type{}) : void()), ...); };
-	if constexpr (PRO == 8)
-		prologue(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
-		         integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{});
-	else
-		prologue(integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
-		         integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{}, integral_constant<int, 8>{}, integral_constant<int, 9>{},
-		         integral_constant<int, 10>{}, integral_constant<int, 11>{}, integral_constant<int, 12>{}, integral_constant<int, 13>{},
-		         integral_constant<int, 14>{}, integral_constant<int, 15>{});
+	for_sequence(
+	    [&](auto k) {
+		    constexpr int I = decltype(k)::value;
+		    if (I < niter) iteration(I, integral_constant<int, I % M>{}, std::true_type{});
+	    },
+	    std::make_integer_sequence<int, PRO>{});
 	int m = PRO;
-	auto group = [&](int m0, auto... ks) { (iteration(m0 + decltype(ks)::value, ks, std::false_type{}), ...); };
-	auto tail = [&](int m0, auto... ks) { ((m0 + decltype(ks)::value < niter ? iteration(m0 + decltype(ks)::value, ks, std::false_type{}) : void()), ...); };
-	if constexpr (M == 4) {
-		for (; m + 3 < niter; m += 4) group(m, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{});
-		tail(m, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{});
-	} else {
-		for (; m + 7 < niter; m += 8)
-			group(m, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
-			      integral_constant<int, 5>{}, integral_constant<int, 6>{}, integral_constant<int, 7>{});
-		tail(m, integral_constant<int, 0>{}, integral_constant<int, 1>{}, integral_constant<int, 2>{}, integral_constant<int, 3>{}, integral_constant<int, 4>{},
-		     integral_constant<int, 5>{}, integral_constant<int, 6>{});
-	}
+	for (; m + M - 1 < niter; m += M)  // steady state: M iterations per trip, every register slot a compile-time constant
+		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::false_type{}); }, std::make_integer_sequence<int, M>{});
+	for_sequence(
+	    [&](auto k) {
+		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::false_type{});
+	    },
+	    std::make_integer_sequence<int, M - 1>{});
 	if constexpr (EMBED) {
 		// wavefront sum in a fixed order (butterfly over lane distances 32 .. 1), one partial per work item: the host-side
 		// reduction adds them in item order, so the norm is reproducible run to run

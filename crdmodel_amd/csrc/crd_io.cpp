@@ -396,3 +396,93 @@ extern "C" int crd_writer_close(crd_writer *w)
 	delete w;
 	return rc;
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Binary side-channel: one NumPy .npy file per slab and variable, <Model>_<surface>_<var>.%03i.npy, holding what the
+// text file holds -- one (nyl, nxl) frame per output time, shape (frames, nyl, nxl), C order, little endian -- at 8 (or 4)
+// bytes per value instead of 24 characters, in the device's own layout (a field plane's owned rows are already this array).
+// The header is a fixed 128-byte block rewritten at close with the number of frames actually written.
+// ---------------------------------------------------------------------------------------------------------------
+struct crd_npy_writer {
+	int fd = -1;
+	int64_t nxl = 0, nyl = 0, frames = 0, off = 128;
+	int value_bytes = 8;
+};
+
+namespace {
+
+bool npy_write_header(const crd_npy_writer *w)
+{
+	char head[128];
+	std::memset(head, ' ', sizeof head);
+	const int n = std::snprintf(head + 10, sizeof head - 10, "{'descr': '<f%d', 'fortran_order': False, 'shape': (%lld, %lld, %lld), }", w->value_bytes,
+	                            (long long)w->frames, (long long)w->nyl, (long long)w->nxl);
+	if (n < 0 || n >= (int)sizeof head - 11) return false;
+	head[10 + n] = ' ';
+	std::memcpy(head, "\x93NUMPY", 6);
+	head[6] = 1;
+	head[7] = 0;
+	head[8] = (char)((sizeof head - 10) & 0xff);
+	head[9] = (char)((sizeof head - 10) >> 8);
+	head[sizeof head - 1] = '\n';
+	return ::pwrite(w->fd, head, sizeof head, 0) == (ssize_t)sizeof head;
+}
+
+}  // namespace
+
+extern "C" int crd_npy_writer_open(const crd_run_config *cfg, const char *dir, int slab, int n_slabs, int var, int value_bytes, crd_npy_writer **out)
+{
+	if (!cfg || !out || (var != 0 && var != 1) || (value_bytes != 4 && value_bytes != 8)) return CRD_EINVAL;
+	*out = nullptr;
+	crd_grid g;
+	int rc = crd_grid_from_params(&cfg->params, &g);
+	if (rc != CRD_OK) return rc;
+	int64_t js, je;
+	rc = crd_slab_extents(g.ny, slab, n_slabs, &js, &je);
+	if (rc != CRD_OK) return rc;
+	if (slab > 999) return CRD_EINVAL;
+	char tag[16];
+	std::snprintf(tag, sizeof tag, ".%03i.npy", slab);
+	const std::string path = std::string(dir && *dir ? dir : ".") + "/" + crd::model_name(cfg->params.model) + "_" + crd::surface_name(cfg->params.surface) + "_" +
+	                         crd::var_name(cfg->params.model, var) + tag;
+	crd_npy_writer *w = new (std::nothrow) crd_npy_writer;
+	if (!w) return CRD_ENOMEM;
+	w->nxl = g.nx;
+	w->nyl = je - js + 1;
+	w->value_bytes = value_bytes;
+	w->fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+	if (w->fd < 0 || !npy_write_header(w)) {
+		crd_npy_writer_close(w);
+		return CRD_EIO;
+	}
+	*out = w;
+	return CRD_OK;
+}
+
+extern "C" int crd_npy_writer_append(crd_npy_writer *w, const void *frame)
+{
+	if (!w || !frame || w->fd < 0) return CRD_EINVAL;
+	const char *p = static_cast<const char *>(frame);
+	size_t len = (size_t)(w->nxl * w->nyl) * (size_t)w->value_bytes;
+	while (len) {
+		const ssize_t k = ::pwrite(w->fd, p, len, (off_t)w->off);
+		if (k <= 0) return CRD_EIO;
+		p += k;
+		len -= (size_t)k;
+		w->off += k;
+	}
+	w->frames++;
+	return CRD_OK;
+}
+
+extern "C" int crd_npy_writer_close(crd_npy_writer *w)
+{
+	if (!w) return CRD_OK;
+	int rc = CRD_OK;
+	if (w->fd >= 0) {
+		if (!npy_write_header(w)) rc = CRD_EIO;  // the frame count as it turned out
+		if (::close(w->fd) != 0) rc = CRD_EIO;
+	}
+	delete w;
+	return rc;
+}

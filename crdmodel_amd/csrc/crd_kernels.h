@@ -90,6 +90,9 @@ hipError_t launch_planes_to_aos(int precision, int dst_is_f64, Planes src, void 
 // Extract var0 of one AoS row into a contiguous row (halo packing for crd_rhs_*).
 hipError_t launch_aos_row_extract(int precision, const void *aos, void *row, int nx, int j, hipStream_t s);
 
+// out = cubic Hermite interpolant at t_n + theta h of the step (yn, fn) -> (yp, fp); owned rows of both fields.
+hipError_t launch_hermite(int precision, Planes yn, Planes yp, Planes fn, Planes fp, Planes out, int nx, int nyl, double theta, double h, hipStream_t s);
+
 // max |u| over the owned rows, written to *out (device double).
 hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s);
 

@@ -358,6 +358,36 @@ hipError_t launch_aos_row_extract(int precision, const void *aos, void *row, int
 	return launch_status();
 }
 
+// Cubic Hermite interpolant of a step [t_n, t_n + h] at theta = (t - t_n) / h from y_n, y_{n+1}, f_n, f_{n+1} (the degree-3
+// dense output ARKode's ARK_NORMAL mode returns, src/FHNmodel_torus.cpp:423): whole planes, ghost rows excluded.
+template <typename Real>
+__global__ void __launch_bounds__(256) crd_hermite_kernel(const Real *__restrict__ yn, const Real *__restrict__ yp, const Real *__restrict__ fn,
+                                                          const Real *__restrict__ fp, Real *__restrict__ out, size_t n, Real h00, Real h10, Real h01, Real h11)
+{
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x)
+		out[q] = fmadd(h00, yn[q], fmadd(h10, fn[q], fmadd(h01, yp[q], h11 * fp[q])));
+}
+
+hipError_t launch_hermite(int precision, Planes yn, Planes yp, Planes fn, Planes fp, Planes out, int nx, int nyl, double theta, double h, hipStream_t s)
+{
+	clear_launch_status();
+	const size_t n = (size_t)nx * (size_t)nyl;
+	if (n == 0) return hipSuccess;
+	const double t2 = theta * theta, t3 = t2 * theta;
+	const double h00 = 2.0 * t3 - 3.0 * t2 + 1.0, h10 = (t3 - 2.0 * t2 + theta) * h, h01 = -2.0 * t3 + 3.0 * t2, h11 = (t3 - t2) * h;
+	const int g = grid_for(n);
+	void *a[5][2] = {{yn.u, yn.v}, {yp.u, yp.v}, {fn.u, fn.v}, {fp.u, fp.v}, {out.u, out.v}};
+	for (int f = 0; f < 2; f++) {
+		if (precision == CRD_PRECISION_F64)
+			crd_hermite_kernel<double><<<g, 256, 0, s>>>(row0<double>(a[0][f], nx), row0<double>(a[1][f], nx), row0<double>(a[2][f], nx), row0<double>(a[3][f], nx),
+			                                           row0<double>(a[4][f], nx), n, h00, h10, h01, h11);
+		else
+			crd_hermite_kernel<float><<<g, 256, 0, s>>>(row0<float>(a[0][f], nx), row0<float>(a[1][f], nx), row0<float>(a[2][f], nx), row0<float>(a[3][f], nx),
+			                                          row0<float>(a[4][f], nx), n, (float)h00, (float)h10, (float)h01, (float)h11);
+	}
+	return launch_status();
+}
+
 hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s)
 {
 	clear_launch_status();

@@ -29,6 +29,8 @@ struct Options {
 	std::string ini;
 	bool quiet = false;
 	int adaptive = -1;
+	bool binary = false;       // also write <Model>_<surface>_<var>.NNN.npy (crd_npy_writer)
+	bool binary_only = false;  // ... and no text rows (the text files are created empty; only crdmodel_amd.post reads such a run)
 };
 
 [[noreturn]] void usage(const char *argv0, bool alias)
@@ -38,7 +40,7 @@ struct Options {
 	} else {
 		std::cerr << "Usage: " << argv0
 		          << " --model fhn|goldbeter --surface torus|flat [--gpus G] [--devices D] [--dt DT] [--stepper auto|staged|fused]\n"
-		             "       [--precision 64|32] [--adaptive|--fixed] [--outdir DIR] [--quiet] <Config file path>\n";
+		             "       [--precision 64|32] [--adaptive|--fixed] [--binary|--binary-only] [--outdir DIR] [--quiet] <Config file path>\n";
 	}
 	std::exit(EXIT_FAILURE);
 }
@@ -167,6 +169,8 @@ int main(int argc, char *argv[])
 			else if (s == "--quiet") o.quiet = true;
 			else if (s == "--adaptive") o.adaptive = 1;
 			else if (s == "--fixed") o.adaptive = 0;
+			else if (s == "--binary") o.binary = true;
+			else if (s == "--binary-only") o.binary = o.binary_only = true;
 			else if (s == "--precision") {
 				const std::string v = next();
 				o.precision = v == "32" ? CRD_PRECISION_F32 : v == "64" ? CRD_PRECISION_F64 : -2;
@@ -232,9 +236,18 @@ int main(int argc, char *argv[])
 	std::vector<std::vector<double>> host((size_t)G), host_b((size_t)G);
 	std::thread writer;
 	int writer_rc = CRD_OK;
+	// Binary side-channel: the owned rows of a field plane ARE the (nyl, nxl) frame of the .npy file, so a frame is one
+	// device-to-host copy into page-locked memory (two sets: one being written to disk, one being filled) -- no layout change,
+	// no formatting.  [slab][var][set]
+	const int nvars_out = 1 + (cfg.include_all_vars == 1 ? 1 : 0);
+	const size_t value_bytes = cfg.params.precision == CRD_PRECISION_F64 ? 8 : 4;
+	std::vector<crd_npy_writer *> npy((size_t)(2 * G), nullptr);
+	std::vector<void *> frame((size_t)(4 * G), nullptr);
 	auto cleanup = [&]() {
 		if (writer.joinable()) writer.join();
 		for (auto *w : wr) crd_writer_close(w);
+		for (auto *w : npy) crd_npy_writer_close(w);
+		for (void *f : frame) crd_host_free(f);
 		for (auto *c : ctx) crd_destroy(c);
 	};
 	for (int k = 0; k < G; k++) {
@@ -271,10 +284,26 @@ int main(int argc, char *argv[])
 			cleanup();
 			return 1;
 		}
-		if ((rc = crd_writer_open(&cfg, o.outdir.c_str(), k, G, &wr[(size_t)k])) != CRD_OK || (rc = crd_writer_write_row(wr[(size_t)k], host[(size_t)k].data())) != CRD_OK) {
+		if ((rc = crd_writer_open(&cfg, o.outdir.c_str(), k, G, &wr[(size_t)k])) != CRD_OK ||
+		    (!o.binary_only && (rc = crd_writer_write_row(wr[(size_t)k], host[(size_t)k].data())) != CRD_OK)) {
 			die("crd_writer", rc, nullptr);
 			cleanup();
 			return 1;
+		}
+		if (o.binary) {
+			const size_t frame_bytes = (size_t)(g.nx * (je - js + 1)) * value_bytes;
+			for (int v = 0; v < nvars_out && rc == CRD_OK; v++) {
+				rc = crd_npy_writer_open(&cfg, o.outdir.c_str(), k, G, v, (int)value_bytes, &npy[(size_t)(2 * k + v)]);
+				for (int set = 0; set < 2 && rc == CRD_OK; set++)
+					if (!(frame[(size_t)(4 * k + 2 * v + set)] = crd_host_alloc(frame_bytes))) rc = CRD_ENOMEM;
+				if (rc == CRD_OK) rc = crd_state_download_rows(ctx[(size_t)k], v, 0, je - js + 1, frame[(size_t)(4 * k + 2 * v)]);
+				if (rc == CRD_OK) rc = crd_npy_writer_append(npy[(size_t)(2 * k + v)], frame[(size_t)(4 * k + 2 * v)]);  // the initial state
+			}
+			if (rc != CRD_OK) {
+				die("crd_npy_writer", rc, ctx[(size_t)k]);
+				cleanup();
+				return 1;
+			}
 		}
 	}
 
@@ -291,6 +320,7 @@ int main(int argc, char *argv[])
 			ao.rtol = cfg.rtol;
 			ao.atol = cfg.atol;
 			ao.h0 = adaptive_h;
+			ao.dense_output = 1;  // ARK_NORMAL: output times do not shorten steps, the row written is the interpolant at tout
 			crd_adaptive_stats as;
 			rc = crd_group_integrate_adaptive(ctx.data(), G, t, (iout + 1 == Nt) ? cfg.t_final : (iout + 1) * dTout, &ao, &as);
 			adaptive_h = as.h_next;
@@ -299,7 +329,14 @@ int main(int argc, char *argv[])
 		} else {
 			rc = crd_group_step_rk4(ctx.data(), G, t, dt, steps_per_output);
 		}
-		for (int k = 0; k < G && rc == CRD_OK; k++) rc = crd_state_download(ctx[(size_t)k], buf[(size_t)k].data(), 1);
+		const int set = (iout + 1) & 1;  // the other set of frame buffers may still be in the writer's hands
+		for (int k = 0; k < G && rc == CRD_OK; k++) {
+			if (!o.binary_only) rc = crd_state_download(ctx[(size_t)k], buf[(size_t)k].data(), 1);
+			int64_t js, je;
+			crd_get_slab(ctx[(size_t)k], &js, &je);
+			for (int v = 0; o.binary && v < nvars_out && rc == CRD_OK; v++)
+				rc = crd_state_download_rows(ctx[(size_t)k], v, 0, je - js + 1, frame[(size_t)(4 * k + 2 * v + set)]);
+		}
 		// the reference stops at the first failing ARKode call on ANY rank (src/FHNmodel_torus.cpp:424-435): look at every slab
 		double peak = 0;
 		for (int k = 0; k < G && rc == CRD_OK; k++) {
@@ -319,8 +356,12 @@ int main(int argc, char *argv[])
 			status = 1;
 			break;
 		}
-		writer = std::thread([&wr, &buf, &writer_rc, G]() {
-			for (int k = 0; k < G && writer_rc == CRD_OK; k++) writer_rc = crd_writer_write_row(wr[(size_t)k], buf[(size_t)k].data());
+		writer = std::thread([&wr, &buf, &writer_rc, &npy, &frame, &o, G, set, nvars_out]() {
+			for (int k = 0; k < G && writer_rc == CRD_OK; k++) {
+				for (int v = 0; o.binary && v < nvars_out && writer_rc == CRD_OK; v++)
+					writer_rc = crd_npy_writer_append(npy[(size_t)(2 * k + v)], frame[(size_t)(4 * k + 2 * v + set)]);
+				if (!o.binary_only && writer_rc == CRD_OK) writer_rc = crd_writer_write_row(wr[(size_t)k], buf[(size_t)k].data());
+			}
 		});
 
 		// progress line, src/FHNmodel_torus.cpp:457-477

@@ -212,6 +212,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 	if (nsteps < 0 || !(dt > 0.0) || !std::isfinite(t0)) return fail(lead, CRD_EINVAL, "bad t0 / dt / nsteps");
 	const int stepper = resolve_stepper(lead);
 	if (stepper < 0) return fail(lead, CRD_EINVAL, "fused stepper not available for this configuration");
+	for (int k = 0; k < n; k++) cs[k]->dense.pending = false;  // stepping on from the state handed back, not from the integrator's internal one
 	for (int k = 0; k < n; k++)
 		if (resolve_stepper(cs[k]) != stepper) return fail(lead, CRD_EINVAL, "contexts of one run disagree on the stepper");
 	int timed = 0;
@@ -328,6 +329,28 @@ int crd_adaptive_defaults(crd_adaptive_options *o)
 	o->shrink = 0.1;
 	o->max_steps = 200000;  // :372
 	o->h_max = 0.0;         // automatic: the diffusion-stability bound
+	o->dense_output = 0;
+	o->reserved = 0;
+	return CRD_OK;
+}
+
+// f(t, plane src) -> plane dst on every slab (bare RHS with the stage kernel; multi-slab: one ghost row of var0 first).
+static int rhs_on_planes(crd_ctx *const *cs, int n, double t, int src, int dst)
+{
+	const bool multi = cs[0]->halo != CRD_HALO_SELF;
+	if (multi)
+		if (int rc = prime_halo(cs, n, src, 1, false)) return rc;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		StageCall call{};
+		call.stage = 0;
+		call.absorb = absorbing(c, t) ? 1 : 0;
+		call.yin = c->planes(src);
+		call.yout = c->planes(dst);
+		if (multi) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+		HIP_TRY(c, launch_stage(c->p.precision, c->desc, call, 0, c->nyl, c->compute));
+	}
 	return CRD_OK;
 }
 
@@ -342,6 +365,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || std::isnan(o.h_max) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0)
 		return fail(lead, CRD_EINVAL, "bad adaptive options / time interval");
 	const bool multi = lead->halo != CRD_HALO_SELF;
+	const bool dense = o.dense_output != 0;
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (!fused_step_supported(c->p.precision, c->desc)) return fail(lead, CRD_EINVAL, "slab too small for the fused step kernel");
@@ -350,14 +374,62 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			c->err_capacity = fused_max_items(c->desc);
 			HIP_TRY(c, hipMalloc((void **)&c->err_partials, sizeof(double) * (size_t)c->err_capacity));
 		}
+		if (dense)
+			for (int f = 0; f < 2; f++)
+				if (!c->plane[crd_ctx::OUT][f]) {
+					HIP_TRY(c, hipMalloc(&c->plane[crd_ctx::OUT][f], c->plane_bytes));
+					HIP_TRY(c, hipMemsetAsync(c->plane[crd_ctx::OUT][f], 0, c->plane_bytes, c->compute));
+				}
 	}
 	crd_adaptive_stats st{};
-	double t = t0;
 	const double h_cap = o.h_max > 0.0 ? o.h_max : (o.h_max == 0.0 ? crd_stable_dt(&lead->p) : INFINITY);
 	double h = std::fmin(o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&lead->p), h_cap);
 	const double n_components = 2.0 * (double)lead->g.nx * (double)lead->g.ny;  // WRMS norm over the whole grid
 	constexpr int kEmbedHalo = kStepHalo + 1;                                     // the fifth stage reads one more row
-	int cur = crd_ctx::Y;
+
+	// Three state planes take turns as y_n, y_{n+1} and scratch: Y and SA (and OUT with dense output).
+	double t = t0;
+	int cur = crd_ctx::Y, spare = crd_ctx::SA, third = dense ? crd_ctx::OUT : -1, prev = -1;
+	double t_prev = t0;
+	const bool resume = dense && lead->dense.pending && t0 == lead->dense.t_out;
+	for (int k = 0; k < n; k++)
+		if (!resume) cs[k]->dense.pending = false;
+	auto hand_back = [&](double theta, double hstep) -> int {  // interpolant of step prev -> cur at t_prev + theta hstep into plane Y, planes re-labelled
+		// roles now: prev = y_n, cur = y_{n+1}, SB = f_n, ACC = f_{n+1}; the interpolant goes to the remaining state plane
+		const int out = crd_ctx::Y + crd_ctx::SA + crd_ctx::OUT - prev - cur;
+		for (int k = 0; k < n; k++) {
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			HIP_TRY(c, launch_hermite(c->p.precision, c->planes(prev), c->planes(cur), c->planes(crd_ctx::SB), c->planes(crd_ctx::ACC), c->planes(out), c->nx, c->nyl,
+			                          theta, hstep, c->compute));
+			void *b_out[2] = {c->plane[out][0], c->plane[out][1]}, *b_n[2] = {c->plane[prev][0], c->plane[prev][1]},
+			     *b_np1[2] = {c->plane[cur][0], c->plane[cur][1]};
+			for (int f = 0; f < 2; f++) {
+				c->plane[crd_ctx::Y][f] = b_out[f];
+				c->plane[crd_ctx::SA][f] = b_np1[f];
+				c->plane[crd_ctx::OUT][f] = b_n[f];
+			}
+		}
+		return CRD_OK;
+	};
+	if (resume) {
+		st.t_internal = lead->dense.t_np1;
+		if (tout <= lead->dense.t_np1) {  // still inside the step the integrator has already taken: interpolate again
+			prev = crd_ctx::OUT;
+			cur = crd_ctx::SA;
+			const double hstep = lead->dense.t_np1 - lead->dense.t_n;
+			if (int rc = hand_back((tout - lead->dense.t_n) / hstep, hstep)) return rc;
+			for (int k = 0; k < n; k++) cs[k]->dense.t_out = tout;
+			st.t = tout;
+			st.h_next = h;
+			if (stats) *stats = st;
+			return CRD_OK;
+		}
+		t = lead->dense.t_np1;
+		cur = crd_ctx::SA;   // the integrator's own state
+		spare = crd_ctx::OUT;  // y_n of the finished step: free
+		third = crd_ctx::Y;    // the interpolant handed back last time: free
+	}
 	bool after_reject = false;
 	int rc = CRD_OK;
 	while (t < tout) {
@@ -367,7 +439,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 		}
 		double hh = h;
 		bool clipped = false;
-		if (t + hh >= tout || tout - (t + hh) < 1e-12 * std::fabs(tout)) {  // land on tout exactly; absorb a sliver of a last step
+		if (!dense && (t + hh >= tout || tout - (t + hh) < 1e-12 * std::fabs(tout))) {  // land on tout exactly; absorb a sliver of a last step
 			hh = tout - t;
 			clipped = true;
 		}
@@ -375,7 +447,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			rc = fail(lead, CRD_ESTATE, "adaptive integration: step size underflow");
 			break;
 		}
-		const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
+		const int dst = spare;
 		if (multi)  // every attempt starts from freshly exchanged ghost rows of the current state (no overlap: the host waits for the norm anyway)
 			if ((rc = prime_halo(cs, n, cur, kEmbedHalo, true))) break;
 		double sum = 0.0;
@@ -411,8 +483,18 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 		else if (err <= 0.0) eta = o.growth;
 		else eta = std::fmin(o.growth, std::fmax(o.shrink, o.safety * std::pow(err, -0.25)));
 		if (err <= 1.0) {
+			t_prev = t;
 			t = clipped ? tout : t + hh;
+			// rotate: the old state becomes y_n (kept for the interpolant), the old y_n / scratch becomes the next target
+			const int old_cur = cur;
 			cur = dst;
+			if (dense) {
+				spare = (prev >= 0) ? prev : third;
+				if (prev < 0) third = -1;
+				prev = old_cur;
+			} else {
+				spare = old_cur;
+			}
 			st.accepted++;
 			if (after_reject) eta = std::fmin(eta, 1.0);  // no growth right after a rejection
 			after_reject = false;
@@ -430,11 +512,29 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			h = hh * std::fmin(eta, 0.9);
 		}
 	}
-	if (cur != crd_ctx::Y)
-		for (int k = 0; k < n; k++) {
-			std::swap(cs[k]->plane[crd_ctx::Y][0], cs[k]->plane[crd_ctx::SA][0]);
-			std::swap(cs[k]->plane[crd_ctx::Y][1], cs[k]->plane[crd_ctx::SA][1]);
+	st.t_internal = t;
+	if (rc == CRD_OK && dense && prev >= 0 && t >= tout) {
+		// ARK_NORMAL: the step t_prev -> t has reached or passed tout.  f at both ends, then the cubic Hermite interpolant at tout.
+		const double hstep = t - t_prev;
+		if ((rc = rhs_on_planes(cs, n, t_prev, prev, crd_ctx::SB)) == CRD_OK && (rc = rhs_on_planes(cs, n, t, cur, crd_ctx::ACC)) == CRD_OK &&
+		    (rc = hand_back((tout - t_prev) / hstep, hstep)) == CRD_OK) {
+			for (int k = 0; k < n; k++) {
+				cs[k]->dense.pending = true;
+				cs[k]->dense.t_out = tout;
+				cs[k]->dense.t_n = t_prev;
+				cs[k]->dense.t_np1 = t;
+			}
+			t = tout;
 		}
+	} else {  // no dense output (or a zero-length interval, or an error): hand back the state reached
+		for (int k = 0; k < n; k++) {
+			if (cur != crd_ctx::Y) {
+				std::swap(cs[k]->plane[crd_ctx::Y][0], cs[k]->plane[cur][0]);
+				std::swap(cs[k]->plane[crd_ctx::Y][1], cs[k]->plane[cur][1]);
+			}
+			cs[k]->dense.pending = false;
+		}
+	}
 	st.t = t;
 	st.h_next = h;
 	if (stats) *stats = st;

@@ -81,7 +81,15 @@ def load_run(directory, model, surface, include_all_vars=False):
         run.subdomains[k] = (i0, i1, j0, j1)
         nxl, nyl = i1 - i0 + 1, j1 - j0 + 1
         for name in names[:2 if include_all_vars else 1]:
-            rows = np.loadtxt(os.path.join(directory, "%s_%s.%03d.txt" % (prefix, name, k)), dtype=np.float64, ndmin=2)
+            # the driver's binary side-channel (`crd_run --binary`), when present, holds the same frames as the text file
+            npy = os.path.join(directory, "%s_%s.%03d.npy" % (prefix, name, k))
+            if os.path.exists(npy):
+                frames = np.load(npy)
+                if frames.ndim != 3 or frames.shape[1:] != (nyl, nxl):
+                    raise ValueError("subdomain %d: %s holds frames of shape %r, expected %r" % (k, npy, frames.shape[1:], (nyl, nxl)))
+                rows = frames.reshape(frames.shape[0], nyl * nxl).astype(np.float64)
+            else:
+                rows = np.loadtxt(os.path.join(directory, "%s_%s.%03d.txt" % (prefix, name, k)), dtype=np.float64, ndmin=2)
             if rows.shape[1] != nxl * nyl:
                 raise ValueError("subdomain %d: rows of %s have %d values, expected %d" % (k, name, rows.shape[1], nxl * nyl))
             if name not in run.fields:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CRD_ABI_VERSION 1
+#define CRD_ABI_VERSION 2
 
 typedef enum crd_status {
 	CRD_OK = 0,
@@ -145,6 +145,15 @@ int crd_writer_open(const crd_run_config *cfg, const char *dir, int slab, int n_
 int crd_writer_write_row(crd_writer *w, const double *y_aos); /* one output time: nyl*nxl values per file */
 int crd_writer_close(crd_writer *w);
 
+/* Binary side-channel next to the text files (no reference counterpart: src/FHNmodel_torus.cpp:438-455 writes 24 characters per
+ * value, 1.6 GB per output time at 8192^2): <Model>_<surface>_<var>.%03i.npy, a NumPy array of shape (frames, nyl, nxl) in the
+ * text file's own ordering (frame = output time, then j, then i), value_bytes = 8 or 4 per value, little endian.  `frame` is a
+ * contiguous (nyl, nxl) block, e.g. what crd_state_download_rows(ctx, var, 0, nyl, frame) delivers. */
+typedef struct crd_npy_writer crd_npy_writer;
+int crd_npy_writer_open(const crd_run_config *cfg, const char *dir, int slab, int n_slabs, int var, int value_bytes, crd_npy_writer **out);
+int crd_npy_writer_append(crd_npy_writer *w, const void *frame);
+int crd_npy_writer_close(crd_npy_writer *w);
+
 /* ---------------------------------------------------------------------------------------------------------
  * Device context: replaces UserData + InitUserData / SetupDecomp / FreeUserData
  * (src/FHNmodel_torus.cpp:97-122,708-772,953-997).  Not thread-safe; calls on one context must be serialised.
@@ -230,8 +239,14 @@ int crd_synchronize(crd_ctx *ctx);
  * the embedded third-order solution y + h (k1/6 + k2/3 + k3/3 + k5/6) and the local error estimate h (k4 - k5)/6, measured
  * in ARKode's WRMS norm with weights 1 / (rtol |y_n| + atol); a step is accepted when bias * norm <= 1 and the next step
  * is safety * h * (bias * norm)^(-1/4), growth-limited (constants in crd_adaptive_options; defaults are ARKode's).
- * Not ARKode's step sequence: its method table and controller are not in the reference tree.  The last step
- * is shortened to land on tout (ARKode overshoots and interpolates).  Multi-slab runs exchange five ghost rows before
+ * Not ARKode's step sequence: its method table and controller are not in the reference tree.
+ * Output times: with dense_output = 0 the last step is shortened to land on tout.  With dense_output = 1 the call does what
+ * ARK_NORMAL does (src/FHNmodel_torus.cpp:423): steps are never shortened for an output time; the integrator steps until it has
+ * reached or passed tout, the state handed back (crd_state_download, the writers) is the cubic Hermite interpolant of the last
+ * step at tout, built from y_n, y_{n+1}, f(t_n, y_n), f(t_{n+1}, y_{n+1}) (ARKode's default dense output is of degree 3 too), and
+ * the integrator's own state stays at its internal time (stats.t_internal >= tout): the next call with t0 equal to this call's
+ * tout continues from there.  Any other call that changes the state (upload, fixed-step stepping, a different t0) drops it.
+ * Multi-slab runs exchange five ghost rows before
  * every attempt and reduce the norm over the ring (ncclAllReduce; LOCAL groups add the slabs' sums on the host in slab
  * order), so every rank takes the same decisions.  h0 = 0 starts from the diffusion-stability step; by default steps are
  * also capped at that bound (h_max = 0), which removes the reject / regrow cycle of a stability-limited explicit method. */
@@ -246,6 +261,8 @@ typedef struct crd_adaptive_options {
 	double h_max;           /* largest step: > 0 explicit cap (ARKodeSetMaxStep); 0 = the classical-RK4 stability bound of the
 	                         * diffusion operator, crd_stable_dt (what ARKodeSetStabilityFn is for: beyond it the error test
 	                         * only finds out by failing); < 0 = no cap, error control alone (ARKode's default) */
+	int32_t dense_output;   /* 0: shorten the last step to hit tout; 1: ARK_NORMAL -- overshoot and interpolate back (see above) */
+	int32_t reserved;
 } crd_adaptive_options;
 typedef struct crd_adaptive_stats {
 	int64_t accepted, rejected;
@@ -253,7 +270,8 @@ typedef struct crd_adaptive_stats {
 	double h_next;          /* controller's suggestion for the next call */
 	double h_min, h_max;    /* over accepted steps */
 	double err_last;        /* bias * WRMS norm of the last attempt */
-	double t;               /* time reached (== tout on success) */
+	double t;               /* time of the state handed back (== tout on success) */
+	double t_internal;      /* time the integrator itself has reached: == t without dense output, >= t with it */
 } crd_adaptive_stats;
 int crd_adaptive_defaults(crd_adaptive_options *opt);
 int crd_integrate_adaptive(crd_ctx *ctx, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats);

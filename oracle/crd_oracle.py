@@ -177,23 +177,45 @@ def rk4(p, y, t0, dt, nsteps, nthreads=1):
     return out
 
 
+def hermite(theta, h, yn, yp, fn, fp):
+    """Cubic Hermite interpolant of a step [t_n, t_n + h] at t_n + theta h (ARKode's degree-3 dense output, ARK_NORMAL,
+    /root/reference/src/FHNmodel_torus.cpp:423), with the coefficients formed as libcrd's launch_hermite forms them."""
+    t2 = theta * theta
+    t3 = t2 * theta
+    h00, h10, h01, h11 = 2.0 * t3 - 3.0 * t2 + 1.0, (t3 - 2.0 * t2 + theta) * h, -2.0 * t3 + 3.0 * t2, (t3 - t2) * h
+    return h00 * yn + (h10 * fn + (h01 * yp + h11 * fp))
+
+
 def integrate_adaptive(p, y, t0, tout, h0, rtol=1e-5, atol=1e-10, safety=0.96, bias=1.5, growth=20.0, shrink=0.1, max_steps=200000, nthreads=1,
-                       h_max=float("inf")):
+                       h_max=float("inf"), dense=None):
     """Error-controlled RK4(3) restated on the CPU for the tests: the step-size logic of libcrd's crd_integrate_adaptive
     around the oracle's f().  Classical RK4 propagates; k5 = f(t+h, y_new) gives the third-order embedded solution
     y + h (k1/6 + k2/3 + k3/3 + k5/6), i.e. the error estimate h (k4 - k5)/6; WRMS norm with weights 1/(rtol |y_n| + atol)
     (the tolerances of /root/reference/src/FHNmodel_torus.cpp:197-198,365).  Steps never exceed h_max (libcrd's default cap is
-    its crd_stable_dt; pass that value to follow it).  Returns (y(tout), stats)."""
+    its crd_stable_dt; pass that value to follow it).  Returns (y(tout), stats).
+    dense: None = the last step is shortened to land on tout.  A dict (start with {}) = ARK_NORMAL: steps are never shortened,
+    the value returned is the cubic Hermite interpolant of the step that passed tout, and the dict carries the integrator's
+    own state (t_n, y_n, t_np1, y_np1, f_n, f_np1) to the next call, which must start at this call's tout."""
     y = np.array(y, dtype=np.float64, order="C", copy=True)
     t, h = float(t0), min(float(h0), h_max)
     st = dict(accepted=0, rejected=0, h_last=0.0, h_min=0.0, h_max=0.0, err_last=0.0, steps=[])
     after_reject = False
     n = y.size
+    y_prev, t_prev = None, t
+    if dense is not None and dense.get("t_out") == t0 and "y_np1" in dense:
+        if tout <= dense["t_np1"]:
+            hs = dense["t_np1"] - dense["t_n"]
+            dense["t_out"] = tout
+            st.update(h_next=h, t=tout, t_internal=dense["t_np1"])
+            return hermite((tout - dense["t_n"]) / hs, hs, dense["y_n"], dense["y_np1"], dense["f_n"], dense["f_np1"]), st
+        t, y = dense["t_np1"], dense["y_np1"]
+    elif dense is not None:
+        dense.clear()
     while t < tout:
         if st["accepted"] + st["rejected"] >= max_steps:
             raise RuntimeError("max_steps")
         hh, clipped = h, False
-        if t + hh >= tout or tout - (t + hh) < 1e-12 * abs(tout):
+        if dense is None and (t + hh >= tout or tout - (t + hh) < 1e-12 * abs(tout)):
             hh, clipped = tout - t, True
         k1 = rhs(p, t, y, nthreads=nthreads)
         k2 = rhs(p, t + 0.5 * hh, y + (0.5 * hh) * k1, nthreads=nthreads)
@@ -211,6 +233,7 @@ def integrate_adaptive(p, y, t0, tout, h0, rtol=1e-5, atol=1e-10, safety=0.96, b
         else:
             eta = min(growth, max(shrink, safety * err ** -0.25))
         if err <= 1.0:
+            y_prev, t_prev = y, t
             t = tout if clipped else t + hh
             y = ynew
             st["accepted"] += 1
@@ -228,5 +251,10 @@ def integrate_adaptive(p, y, t0, tout, h0, rtol=1e-5, atol=1e-10, safety=0.96, b
             after_reject = True
             h = hh * min(eta, 0.9)
     st["h_next"] = h
-    st["t"] = t
+    st["t"] = st["t_internal"] = t
+    if dense is not None and y_prev is not None and t >= tout:
+        hs = t - t_prev
+        dense.update(t_out=tout, t_n=t_prev, t_np1=t, y_n=y_prev, y_np1=y, f_n=rhs(p, t_prev, y_prev, nthreads=nthreads), f_np1=rhs(p, t, y, nthreads=nthreads))
+        st["t"] = tout
+        return hermite((tout - t_prev) / hs, hs, y_prev, y, dense["f_n"], dense["f_np1"]), st
     return y, st

@@ -28,7 +28,7 @@ int main(int argc, char **argv)
 {
 	CHECK(argc == 2);
 	const std::string dir = argv[1];
-	CHECK(crd_abi_version() == 1);
+	CHECK(crd_abi_version() == CRD_ABI_VERSION);
 	for (int st = 1; st >= -9; st--) CHECK(crd_status_string(st) != nullptr);
 
 	// ---- ini files: a complete one, odd spacing / comments, missing key, malformed number, missing file, tiny err buffer
@@ -176,6 +176,24 @@ int main(int argc, char **argv)
 			CHECK(std::isnan(want) ? std::isnan(v) : v == want);
 		}
 		std::fclose(f);
+	}
+	{  // binary side-channel: header, three frames, header rewritten at close
+		crd_npy_writer *nw = nullptr;
+		CHECK(crd_npy_writer_open(&cfg, dir.c_str(), 1, 2, 1, 8, &nw) == CRD_OK && nw);
+		CHECK(crd_slab_extents(40, 1, 2, &js, &je) == CRD_OK);
+		std::vector<double> fr((size_t)16 * (size_t)(je - js + 1), 1.5);
+		for (int t = 0; t < 3; t++) CHECK(crd_npy_writer_append(nw, fr.data()) == CRD_OK);
+		CHECK(crd_npy_writer_append(nw, nullptr) != CRD_OK);
+		CHECK(crd_npy_writer_close(nw) == CRD_OK);
+		FILE *f = std::fopen((dir + "/FHNmodel_torus_v.001.npy").c_str(), "rb");
+		CHECK(f);
+		char head[128];
+		CHECK(std::fread(head, 1, sizeof head, f) == sizeof head && std::memcmp(head, "\x93NUMPY", 6) == 0 && head[127] == '\n');
+		CHECK(std::string(head + 10, 117).find("'shape': (3, 20, 16)") != std::string::npos);
+		std::fseek(f, 0, SEEK_END);
+		CHECK(std::ftell(f) == 128 + 3 * 20 * 16 * 8);
+		std::fclose(f);
+		CHECK(crd_npy_writer_open(&cfg, dir.c_str(), 0, 1, 0, 5, &nw) != CRD_OK && crd_npy_writer_close(nullptr) == CRD_OK);
 	}
 	crd_writer *w = nullptr;
 	CHECK(crd_writer_open(&cfg, (dir + "/no/such/dir").c_str(), 0, 1, &w) != CRD_OK && w == nullptr);

@@ -56,8 +56,9 @@ def test_driver_writes_reference_format(gpu_device, tmp_path, argv):
 
 
 def test_driver_adaptive_mode(gpu_device, tmp_path):
-    """`--adaptive`: one error-controlled integration per output interval (as the reference calls ARKode once per output),
-    the controller's step carried from interval to interval; checked against the CPU restatement of the same controller."""
+    """`--adaptive`: one error-controlled integration per output interval (as the reference calls ARKode once per output, in
+    ARK_NORMAL mode: output times do not shorten steps, the rows written are interpolants), the controller's step carried from
+    interval to interval; checked against the CPU restatement of the same controller and interpolant."""
     cfg = crd.load_ini(INI, "fhn", "torus")
     r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--adaptive", INI], cwd=tmp_path, capture_output=True,
                        text=True, timeout=300)
@@ -67,10 +68,11 @@ def test_driver_adaptive_mode(gpu_device, tmp_path):
     g = crd.grid_of(p)
     op = co.make_problem(co.FHN, co.TORUS, g.nx, p.surface_length, p.surface_width, p.diffusion, p.beta, ny=p.ny, t_boundary=p.t_boundary)
     y = co.initial_conditions(op, cfg.wave_length, cfg.wave_width, cfg.wave_inside, 0)
-    frames, h = [y], 0.8 * crd.stable_dt(p)
+    frames, h, dense = [y], 0.8 * crd.stable_dt(p), {}
     d_tout = cfg.t_final / cfg.output_timestep
     for k in range(cfg.output_timestep):
-        y, st = co.integrate_adaptive(op, y, k * d_tout, cfg.t_final if k + 1 == cfg.output_timestep else (k + 1) * d_tout, h)
+        y, st = co.integrate_adaptive(op, y, k * d_tout, cfg.t_final if k + 1 == cfg.output_timestep else (k + 1) * d_tout, h, h_max=crd.stable_dt(p),
+                                      dense=dense)
         h = st["h_next"]
         frames.append(y)
     want = np.stack(frames)
@@ -128,3 +130,43 @@ def test_driver_started_by_an_mpi_launcher(gpu_device, tmp_path):
     assert run.subdomains.shape == (2, 4)
     want = oracle_outputs(cfg)
     assert rel_err(run.fields["u"], want[..., 0]) <= 1e-9 and rel_err(run.fields["v"], want[..., 1]) <= 1e-9
+
+
+def test_compiled_arkrhsfn_shim(gpu_device, tmp_path):
+    """integration/crd_arkode_shim.c -- the reference's `f(t, y, ydot, user_data)` bound to libcrd -- compiled as C and driven
+    through an `ARKRhsFn`-typed pointer by an explicit RK4 loop on host N_Vector arrays (tests/native/shim_selftest.c, with a
+    test double for the two SUNDIALS names the shim uses): the trajectory equals the resident-state stepper's to round-off."""
+    exe = tmp_path / "shim_selftest"
+    lib_dir = os.path.join(ROOT, "crdmodel_amd")
+    cmd = ["gcc", "-std=c99", "-O1", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "integration"),
+           "-I", os.path.join(ROOT, "tests", "native"), '-DCRD_SHIM_NVECTOR_HEADER="mock_nvector.h"',
+           os.path.join(ROOT, "integration", "crd_arkode_shim.c"), os.path.join(ROOT, "tests", "native", "shim_selftest.c"), "-o", str(exe),
+           "-L", lib_dir, "-lcrd", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    build = subprocess.run(cmd, capture_output=True, text=True)
+    assert build.returncode == 0, build.stderr
+    r = subprocess.run([str(exe), INI], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.stdout, r.stderr)
+    assert "through the ARKRhsFn" in r.stdout
+
+
+def test_driver_binary_side_channel(gpu_device, tmp_path):
+    """`crd_run --binary`: <Model>_<surface>_<var>.NNN.npy next to the byte-compatible text files holds the same frames (the
+    text's %.16e round-trips doubles exactly, so the two must agree bit for bit); `--binary-only` writes no text rows and the
+    Python-3 loader stitches the run from the .npy files alone."""
+    from crdmodel_amd import post
+
+    both = tmp_path / "both"
+    only = tmp_path / "only"
+    for d, flag in ((both, "--binary"), (only, "--binary-only")):
+        d.mkdir()
+        r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--gpus", "2", "--devices", "1", flag, "--quiet", INI],
+                           cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+    u_text, meta = load_like_the_plot_script(both, "FHNmodel_torus", "u")
+    for k in range(2):
+        frames = np.load(both / ("FHNmodel_torus_u.%03d.npy" % k))
+        rows = np.loadtxt(both / ("FHNmodel_torus_u.%03d.txt" % k), ndmin=2)
+        assert frames.dtype == np.float64 and np.array_equal(frames.reshape(frames.shape[0], -1), rows)
+        assert os.path.getsize(only / ("FHNmodel_torus_u.%03d.txt" % k)) == 0
+    run = post.load_run(str(only), "fhn", "torus")
+    assert np.array_equal(run.fields["u"], u_text)

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and the ctypes table binds exactly the declared set, so a header change cannot go unbound
     assert sorted(crd._capi._SIGNATURES) == names
-    assert crd._capi.lib().crd_abi_version() == 1
+    assert crd._capi.lib().crd_abi_version() == 2
 
 
 def test_status_strings():
@@ -223,3 +223,20 @@ int main(void) {
     assert r.returncode == 0, (r.returncode, r.stderr)
     assert r.stdout.split()[:3] == ["ini", "parse", "error"]
     assert int(r.stdout.split()[-1]) == C.sizeof(crd._capi.RunConfig)  # the ctypes mirror has the C layout
+
+
+def test_arkrhsfn_shim_compiles_as_c(tmp_path):
+    """integration/crd_arkode_shim.c is plain C against include/crd.h: it compiles (with the test double for the two SUNDIALS
+    names it uses) and links against libcrd; running it needs a GPU (tests/test_gpu_driver.py)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    lib_dir = os.path.join(ROOT, "crdmodel_amd")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "integration"),
+           "-I", os.path.join(ROOT, "tests", "native"), '-DCRD_SHIM_NVECTOR_HEADER="mock_nvector.h"',
+           os.path.join(ROOT, "integration", "crd_arkode_shim.c"), os.path.join(ROOT, "tests", "native", "shim_selftest.c"),
+           "-o", str(tmp_path / "shim"), "-L", lib_dir, "-lcrd", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

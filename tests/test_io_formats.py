@@ -96,3 +96,33 @@ def test_driver_under_an_mpi_launcher_leaves_the_work_to_rank_zero(tmp_path):
                            env=dict(os.environ, **env), timeout=60)
         assert r.returncode == 0 and r.stdout == "" and r.stderr == ""
         assert os.listdir(tmp_path) == []
+
+
+@pytest.mark.parametrize("value_bytes", [8, 4])
+def test_npy_side_channel_round_trip(tmp_path, value_bytes):
+    """crd_npy_writer: one .npy per slab and variable holding the text file's frames; numpy reads it back exactly, the frame
+    count in the header is the number of frames actually appended, and the post-processing loader prefers it over the text."""
+    import ctypes as C
+
+    L = crd._capi.lib()
+    p = crd.make_params("goldbeter", "flat", 12, 20.0, 20.0, 0.12, 0.4, precision="f64")
+    cfg = crd.run_config(p, output_timestep=5, t_final=1.0)
+    g = crd.grid_of(p)
+    dtype = np.float64 if value_bytes == 8 else np.float32
+    rng = np.random.default_rng(5)
+    for slab in range(2):
+        js, je = crd.slab_extents(g.ny, slab, 2)
+        frames = rng.standard_normal((3, je - js + 1, g.nx)).astype(dtype)
+        for var, name in ((0, "Z"), (1, "Y")):
+            h = C.c_void_p()
+            assert L.crd_npy_writer_open(C.byref(cfg), str(tmp_path).encode(), slab, 2, var, value_bytes, C.byref(h)) == 0
+            for f in frames:
+                f = np.ascontiguousarray(f + var)
+                assert L.crd_npy_writer_append(h, f.ctypes.data) == 0
+            assert L.crd_npy_writer_close(h) == 0
+            back = np.load(tmp_path / ("GoldbeterModel_flat_%s.%03d.npy" % (name, slab)))
+            assert back.dtype == dtype and back.shape == frames.shape and np.array_equal(back, frames + var)
+    h = C.c_void_p()
+    assert L.crd_npy_writer_open(C.byref(cfg), str(tmp_path / "nope").encode(), 0, 1, 0, 8, C.byref(h)) != 0 and not h
+    assert L.crd_npy_writer_open(C.byref(cfg), str(tmp_path).encode(), 0, 1, 2, 8, C.byref(h)) != 0
+    assert L.crd_npy_writer_open(C.byref(cfg), str(tmp_path).encode(), 0, 1, 0, 3, C.byref(h)) != 0
