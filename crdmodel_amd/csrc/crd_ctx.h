@@ -7,7 +7,10 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>  // types and prototypes only; the library is bound with dlopen at first use
 
+#include <atomic>
+#include <condition_variable>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -38,6 +41,43 @@ struct RcclApi {
 extern RcclApi g_rccl;
 
 }  // namespace crd
+
+// Rendezvous of the issuing threads of a LOCAL group (crd_group_step_rk4 with one host thread per device).  A stream may
+// only be told to wait for an event AFTER the thread that records it has enqueued the record; the threads meet here between
+// "everybody has recorded" and "everybody waits".  A thread that fails leaves the group and raises `abort`; the others see it
+// at their next rendezvous and give up too, so nobody waits for a thread that is gone.
+struct GroupBarrier {
+	std::mutex m;
+	std::condition_variable cv;
+	int members = 0, arrived = 0;
+	unsigned generation = 0;
+	std::atomic<int> abort{0};
+
+	bool wait()  // false: another thread has failed
+	{
+		std::unique_lock<std::mutex> lk(m);
+		const unsigned g = generation;
+		if (++arrived >= members) {
+			arrived = 0;
+			generation++;
+			cv.notify_all();
+		} else {
+			cv.wait(lk, [&] { return generation != g; });
+		}
+		return abort.load() == 0;
+	}
+	void leave_failed()
+	{
+		std::unique_lock<std::mutex> lk(m);
+		abort.store(1);
+		members--;
+		if (members > 0 && arrived >= members) {
+			arrived = 0;
+			generation++;
+		}
+		cv.notify_all();
+	}
+};
 
 // The three streams of a context: interior sweeps, edge bands (high priority), halo exchange.  Contexts of a LOCAL group
 // that share a device share one set (crd_comm_attach_local), so a device never carries more than three of this library's
@@ -102,6 +142,7 @@ struct crd_ctx {
 
 	int halo = CRD_HALO_SELF;
 	std::vector<crd_ctx *> group;  // LOCAL: all contexts of the run, by slab index
+	GroupBarrier *bar = nullptr;   // set while several host threads issue for the group (crd_group_step_rk4)
 	ncclComm_t nccl = nullptr;
 
 	std::string err;

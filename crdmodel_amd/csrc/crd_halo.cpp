@@ -91,6 +91,10 @@ int exchange_local_pull(crd_ctx *c, int plane_index, int depth, bool with_v)
 // the transfers and record each context's halo event; the caller orders the compute streams against those events.
 int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_v)
 {
+	// Several issuing threads (one per device of a LOCAL group): every thread has enqueued the records of its contexts'
+	// edge events before any thread makes a stream wait for a neighbour's.
+	GroupBarrier *bar = cs[0]->bar;
+	if (bar && !bar->wait()) return fail(cs[0], CRD_ESTATE, "another slab's issuing thread failed");
 	// comm streams wait for the producers of the edge rows
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
@@ -111,6 +115,8 @@ int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, 
 		if (rc) return rc;
 		HIP_TRY(c, hipEventRecord(c->ev_halo, c->comm));
 	}
+	// ... and every halo event is on record before any thread makes a stream wait for a neighbour's
+	if (bar && !bar->wait()) return fail(cs[0], CRD_ESTATE, "another slab's issuing thread failed");
 	return CRD_OK;
 }
 

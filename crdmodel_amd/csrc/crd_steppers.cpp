@@ -2,6 +2,8 @@
 // slab or on the slabs of a run (deep-halo exchange cycles), and the error-controlled RK4(3) integrator.  Host code only.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <thread>
 
 #include "crd_ctx.h"
 
@@ -264,6 +266,8 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			}
 			if (timed_step) timed = 1;
 		}
+		// (several issuing threads: the neighbours read this thread's plane pointers while they enqueue their pulls)
+		if (lead->bar && !lead->bar->wait()) return fail(lead, CRD_ESTATE, "another slab's issuing thread failed");
 		if (cur != crd_ctx::Y)
 			for (int k = 0; k < n; k++) {
 				std::swap(cs[k]->plane[crd_ctx::Y][0], cs[k]->plane[crd_ctx::SA][0]);
@@ -308,13 +312,50 @@ int crd_step_rk4(crd_ctx *c, double t0, double dt, int64_t nsteps)
 	return run_steps(one, 1, t0, dt, nsteps, nullptr);
 }
 
+// LOCAL groups spread over several devices get one issuing thread per device: a single thread that enqueues every launch, event
+// and peer copy of every GPU becomes the bottleneck once a GPU's share of a step is short (an 8192 x 1024 slab steps in ~60 us,
+// a thread needs a good part of that to issue one GPU's work).  The threads run the same step loop on their own contexts and meet
+// at the group's rendezvous around every halo exchange.  CRD_GROUP_THREADS=k forces k threads (also on one device: a test knob),
+// CRD_GROUP_THREADS=1 the single-thread path.
 int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps)
 {
 	if (int rc = check_group(ctxs, n)) return rc;
 	if (n > 1)
 		for (int k = 0; k < n; k++)
 			if (ctxs[k]->halo != CRD_HALO_LOCAL) return fail(ctxs[0], CRD_ESTATE, "group is not attached");
-	return run_steps(ctxs, n, t0, dt, nsteps, nullptr);
+	// contiguous runs of slabs per thread: by device, or by the knob
+	std::vector<int> first{0};
+	int forced = 0;
+	if (const char *e = std::getenv("CRD_GROUP_THREADS")) forced = std::atoi(e);
+	if (forced > 1) {
+		const int t = std::min(forced, n);
+		for (int q = 1; q < t; q++) first.push_back((int)((long)n * q / t));
+	} else if (forced == 0) {
+		for (int k = 1; k < n; k++)
+			if (ctxs[k]->device != ctxs[k - 1]->device) first.push_back(k);
+	}
+	const int nthreads = (int)first.size();
+	if (nthreads <= 1 || nsteps <= 0) return run_steps(ctxs, n, t0, dt, nsteps, nullptr);
+	first.push_back(n);
+	GroupBarrier bar;
+	bar.members = nthreads;
+	for (int k = 0; k < n; k++) ctxs[k]->bar = &bar;
+	std::vector<int> rcs((size_t)nthreads, CRD_OK);
+	auto work = [&](int q) {
+		rcs[(size_t)q] = run_steps(ctxs + first[(size_t)q], first[(size_t)q + 1] - first[(size_t)q], t0, dt, nsteps, nullptr);
+		if (rcs[(size_t)q] != CRD_OK) bar.leave_failed();
+	};
+	std::vector<std::thread> pool;
+	for (int q = 1; q < nthreads; q++) pool.emplace_back(work, q);
+	work(0);
+	for (auto &th : pool) th.join();
+	for (int k = 0; k < n; k++) ctxs[k]->bar = nullptr;
+	for (int q = 0; q < nthreads; q++)
+		if (rcs[(size_t)q] != CRD_OK) {
+			if (q > 0 && ctxs[0]->err.empty()) ctxs[0]->err = ctxs[first[(size_t)q]]->err;  // the caller asks the first context for the text
+			return rcs[(size_t)q];
+		}
+	return CRD_OK;
 }
 
 int crd_adaptive_defaults(crd_adaptive_options *o)
