@@ -116,6 +116,7 @@ struct FusedArgs {
 	int nchunks1;             // chunks of the first range
 	int chunk;                // rows per work item
 	int nstrips, nitems, nblocks, remap;
+	int xs_lanes;             // remap 2: phi-lanes of chunk sequences per strip block and XCD
 	int nchunks;              // chunks of both ranges
 	int sw;                   // wavefronts per block = adjacent strips a block covers
 	int lockstep;             // the block's wavefronts march in step (one barrier per pipeline iteration)
@@ -155,15 +156,15 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	const int nsb = (a.nstrips + a.sw - 1) / a.sw;
 	int sblk = blk % nsb, cblk = blk / nsb;
 	if (a.remap == 2) {
-		// Chunks in groups of eight, one chunk per XCD: block ids 8k + x of a group (workgroups are dealt round-robin over the
-		// XCDs, and a group holds a multiple of eight blocks) cover strip block k of the group's chunk x, so theta-neighbouring
-		// blocks share an L2 and fetch their common apron columns from beyond it once.  The last, partial group keeps chunk order.
-		const int group = kNumXcd * nsb, g = blk / group;
-		if ((g + 1) * kNumXcd <= a.nchunks) {
-			const int r = blk - g * group;
-			sblk = r / kNumXcd;
-			cblk = g * kNumXcd + r % kNumXcd;
-		}
+		// Succession in phi: XCD x owns a contiguous run of chunks; its resident workgroups form `xs_lanes` lanes per strip
+		// block, and the workgroup that takes a finished one's place (ids are dispatched in order, 8 apart on one XCD) continues
+		// that lane with the NEXT chunk in phi -- whose first rows are the rows its predecessor has just read into this L2.
+		const int x = blk % kNumXcd, p = blk / kNumXcd, width = nsb * a.xs_lanes;
+		const int d = p / width, sl = p - d * width;
+		const int c0 = (int)((long)a.nchunks * x / kNumXcd), c1 = (int)((long)a.nchunks * (x + 1) / kNumXcd);
+		const int depth = (c1 - c0 + a.xs_lanes - 1) / a.xs_lanes, lane_id = sl / nsb;
+		sblk = sl - lane_id * nsb;
+		cblk = (d < depth && c0 + lane_id * depth + d < c1) ? c0 + lane_id * depth + d : a.nchunks;  // a.nchunks: nothing to do
 	}
 	const int strip = __builtin_amdgcn_readfirstlane(sblk * a.sw + (int)(threadIdx.x >> 6));
 	const int chunk = __builtin_amdgcn_readfirstlane(cblk);
@@ -377,7 +378,7 @@ const char *tuning_knob(const char *name) { return tuning_enabled() ? std::geten
 // `one_round` (a launch-plan choice, see FusedPlan): a launch that needs more than one round of resident blocks but would
 // fit into one with chunks of up to 96 rows gets those longer chunks -- no tail round on an almost idle chip.
 template <typename Real, int MODEL>
-int fused_chunk_rows(int nstrips, int rows, bool one_round)
+int resident_wavefronts()
 {
 	static int slots = 0;  // resident wavefronts of this kernel on the current device
 	if (slots == 0) {
@@ -390,6 +391,13 @@ int fused_chunk_rows(int nstrips, int rows, bool one_round)
 		(void)hipGetLastError();
 		slots = cus * blocks_per_cu * kWavesPerBlock;
 	}
+	return slots;
+}
+
+template <typename Real, int MODEL>
+int fused_chunk_rows(int nstrips, int rows, bool one_round)
+{
+	const int slots = resident_wavefronts<Real, MODEL>();
 	int chunk = 32;
 	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
 	if (const char *e = tuning_knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
@@ -405,12 +413,16 @@ int fused_chunk_rows(int nstrips, int rows, bool one_round)
 	return chunk < rows ? chunk : rows;
 }
 
-// Launch-plan candidates the autotuner times: (chunks stretched to one round?, block -> item mapping).  Mapping 0 walks the
-// items theta-first in dispatch order; 1 gives each XCD one contiguous run of items (a contiguous band of the slab: phi- and
-// theta-neighbouring items then share an L2); 2 deals chunks round-robin to the XCDs in groups of eight.  Which one is
-// fastest depends on the grid shape AND on the device: on 8192^2 fp64 mapping 1 measured -6.3 %, -0.7 % and +1.7 % against
-// mapping 0 on three MI355X of the same pool, one-round chunks -10 % (4096 x 1024) to +2 % (16384 x 2048 fp32) -- hence
-// measured at run time, on the device and the shape at hand.  Every candidate computes bit-identical results.
+// Launch-plan candidates the autotuner times: (chunks stretched to one round?, block -> item mapping).  Workgroups are dealt
+// round-robin to the 8 XCDs, each with its own L2.  Mapping 0 walks the items theta-first in dispatch order: neighbouring
+// items land on different XCDs and every apron column and row is fetched from beyond L2 by both items that need it (PMC:
+// 39.5 B per point, reads 1.47 x the plane).  Mapping 1 gives each XCD one contiguous run of items, i.e. a contiguous band of
+// the slab: theta-neighbours share an L2 and the apron columns are fetched once (36.6 B per point, reads 1.29 x).  Mapping 2
+// adds succession in phi -- the workgroup that takes a finished one's place continues with the next chunk in phi, whose first
+// rows its predecessor has just pulled into that L2 (34.9 B per point, reads 1.18 x).  Which plan is fastest depends on the
+// grid shape AND on the device: on 8192^2 fp64 mapping 1 measured -6.3 %, -0.7 % and +1.7 % against mapping 0 on three
+// MI355X of the same pool, mapping 2 -4.4 % on a fourth; one-round chunks -10 % (4096 x 1024) to +2 % (16384 x 2048 fp32) --
+// hence measured at run time, on the device and the shape at hand.  Every candidate computes bit-identical results.
 struct PlanCandidate {
 	int one_round, remap;
 };
@@ -472,6 +484,17 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		a.nblocks = ((a.nstrips + sw - 1) / sw) * a.nchunks;
 		a.remap = remap;
 		if (const char *e = tuning_knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);  // tuning knob
+		a.xs_lanes = 1;
+		if (a.remap == 2) {
+			const int nsb = (a.nstrips + sw - 1) / sw, per_xcd = resident_wavefronts<Real, MODEL>() / sw / kNumXcd;
+			if (rows2 > 0 || a.nchunks < 2 * kNumXcd || per_xcd < nsb) {
+				a.remap = 0;  // two row ranges, or too few chunks / slots for lanes: plain order
+			} else {
+				a.xs_lanes = per_xcd / nsb;
+				const int most = (a.nchunks + kNumXcd - 1) / kNumXcd;  // chunks of the best-served XCD
+				a.nblocks = kNumXcd * ((most + a.xs_lanes - 1) / a.xs_lanes) * nsb * a.xs_lanes;
+			}
+		}
 	};
 	auto fire = [&]() -> hipError_t {
 		if (c.embed) {

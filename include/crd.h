@@ -307,7 +307,7 @@ typedef struct crd_launch_plan {
 	int32_t autotune;     /* measuring enabled */
 	int32_t tuned;        /* a measurement has been made */
 	int32_t one_round;    /* chunks stretched so that all workgroups are resident at once */
-	int32_t xcd_mapping;  /* 0 theta-first dispatch order, 1 one contiguous band of the slab per XCD, 2 chunks dealt to XCDs in groups of 8 */
+	int32_t xcd_mapping;  /* 0 theta-first dispatch order, 1 one contiguous band of the slab per XCD, 2 the same with succession in phi */
 	int32_t rows;         /* height of the launch it was measured on */
 	int32_t reserved;
 	double ms_default, ms_chosen; /* measured launch times: plain plan, chosen plan */
