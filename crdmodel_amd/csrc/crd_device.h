@@ -69,8 +69,10 @@ __device__ __forceinline__ double fmadd(double a, double b, double c) { return _
 __device__ __forceinline__ float fmadd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
 // 1 / x for a positive, normal x well inside the exponent range (here x >= K2^2 KR^2 KA^4 = 2.6): the hardware estimate
-// refined by two Newton steps, i.e. the core of the compiler's division sequence without the scaling and special-case
-// instructions around it (11 -> 5 instructions per reciprocal; the result is within 1 ulp of the rounded quotient).
+// (v_rcp_f64: relative error 2^-24.4, and 3.3 times the issue cost of an fp64 FMA -- tools/rcp_probe.hip) refined by ONE Newton
+// step: relative error <= 2.2e-15 = 2^-48.7 measured over [2.6, 1e6], three orders of magnitude inside the 1e-12 parity
+// tolerance of a right-hand side, for 3 instructions against the 11 of the compiler's correctly rounded division (a second
+// step, CRD_RCP_NEWTON=2, brings 2^-53 for two more).
 #ifndef CRD_RCP_NEWTON
 #define CRD_RCP_NEWTON 1
 #endif
@@ -118,18 +120,10 @@ __device__ __forceinline__ void rhs_point(Real uC, Real uW, Real uE, Real uS, Re
 		// the kinetics against 27 with the two Hill terms formed separately (this kernel is bound by fp64 issue).
 		const Real z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
 		const Real dA = (Real)(kGbK2 * kGbK2) + z2, dB = ((Real)(kGbKr * kGbKr) + y2) * (ka4 + z4);
-#ifdef CRD_GB_TWO_QUOTIENTS  // A/B only
-		const Real rinv = reciprocal(dA * dB);
-		const Real v2 = ((Real)kGbVm2 * z2) * (dB * rinv);
-		const Real v3 = (((Real)kGbVm3 * y2) * z4) * (dA * rinv);
-		du = diff + fmadd(-(Real)kGbK, uC, ((rowp - v2) + v3) + (Real)kGbKf * v);
-		dv = (v2 - v3) - (Real)kGbKf * v;
-#else
 		const Real n2 = ((Real)kGbVm2 * z2) * dB, n3 = (((Real)kGbVm3 * y2) * z4) * dA;
 		const Real w = (n2 - n3) * reciprocal(dA * dB);
 		dv = w - (Real)kGbKf * v;
 		du = diff + fmadd(-(Real)kGbK, uC, rowp - dv);  // rowp = v0 + v1 b
-#endif
 	}
 	if (zero) {
 		du = (Real)0;

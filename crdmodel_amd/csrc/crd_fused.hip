@@ -91,6 +91,17 @@ __device__ __forceinline__ void for_sequence(F &&f, std::integer_sequence<int, I
 	(f(std::integral_constant<int, Is>{}), ...);
 }
 
+// row base (uniform) + this lane's byte offset
+template <typename T>
+__device__ __forceinline__ T *at_lane(T *row, unsigned byte_offset)
+{
+	using Bytes = std::conditional_t<std::is_const<T>::value, const char, char>;
+	// (the empty asm keeps the compiler from hoisting `constant pointer + lane offset` out of the row loop as a 64-bit vector
+	// base, which would cost a 64-bit vector add per access to put the row offset back in)
+	asm volatile("" : "+v"(byte_offset));
+	return reinterpret_cast<T *>(reinterpret_cast<Bytes *>(row) + byte_offset);
+}
+
 // A value known to be identical in every lane, moved to scalar registers.
 __device__ __forceinline__ double uniform(double x)
 {
@@ -98,11 +109,8 @@ __device__ __forceinline__ double uniform(double x)
 }
 __device__ __forceinline__ float uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
 
-#ifdef CRD_NT_LOADS  // A/B only: non-temporal row loads
-#define CRD_ROW_LOAD(p) __builtin_nontemporal_load(p)
-#else
+// (non-temporal row loads measured 19 % slower, fp64 and fp32 alike: the apron rows and columns two items share come from cache)
 #define CRD_ROW_LOAD(p) (*(p))
-#endif
 
 template <typename Real>
 struct FusedArgs {
@@ -175,6 +183,9 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	int x = strip * VALID - APRON + lane;  // this lane's column, wrapped periodically (nx may be smaller than 64)
 	x %= nx;
 	if (x < 0) x += nx;
+	// lane offsets in bytes, unsigned 32-bit: with a scalar row base the accesses take the `global_load v, v_off, s[base]` form and
+	// no 64-bit vector add is spent per access
+	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real), ob = (unsigned)(strip * VALID + (lane - APRON)) * (unsigned)sizeof(Real);
 	const int out_col = strip * VALID + (lane - APRON);
 	const bool lane_stores = lane >= APRON && lane < kLanes - APRON && out_col < nx;
 
@@ -226,8 +237,8 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	for (int k = 0; k < kPrefetch; k++) {
 		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
 		const ptrdiff_t rb = row_base(jr);
-		pu[k] = CRD_ROW_LOAD(a.in_u + rb + x);
-		pv[k] = CRD_ROW_LOAD(a.in_v + rb + x);
+		pu[k] = CRD_ROW_LOAD(at_lane(a.in_u + rb, xb));
+		pv[k] = CRD_ROW_LOAD(at_lane(a.in_v + rb, xb));
 		pb[k] = brow[jr];
 	}
 #pragma unroll
@@ -251,8 +262,8 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		{
 			const int pn = (p + kPrefetch < jlast) ? p + kPrefetch : jlast;  // the tail re-reads a valid row instead of running past the plane
 			const ptrdiff_t rb = row_base(pn);
-			pu[P] = CRD_ROW_LOAD(a.in_u + rb + x);
-			pv[P] = CRD_ROW_LOAD(a.in_v + rb + x);
+			pu[P] = CRD_ROW_LOAD(at_lane(a.in_u + rb, xb));
+			pv[P] = CRD_ROW_LOAD(at_lane(a.in_v + rb, xb));
 			pb[P] = brow[pn];
 		}
 		Real du, dv;
@@ -293,9 +304,9 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);
 			const Real nu = fmadd(a.h6, du, aU[S4]), nv = fmadd(a.h6, dv, aV[S4]);
 			if ((EMBED ? (c >= j0 && c < j1) : c < j1) && lane_stores) {  // without the fifth stage c >= j0 holds from iteration 8 on
-				const ptrdiff_t o = (ptrdiff_t)c * nx + out_col;
-				a.out_u[o] = nu;
-				a.out_v[o] = nv;
+				const ptrdiff_t o = (ptrdiff_t)c * nx;
+				*at_lane(a.out_u + o, ob) = nu;
+				*at_lane(a.out_v + o, ob) = nv;
 			}
 			if (EMBED) {
 				U4[S4] = nu;
