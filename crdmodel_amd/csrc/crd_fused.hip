@@ -33,7 +33,7 @@ constexpr int kApron = 4;                    // RK4 stages = halo depth
 constexpr int kLanes = 64;
 constexpr int kValid = kLanes - 2 * kApron;  // 56 output columns per wavefront
 constexpr int kWavesPerBlock = 4;     // default; the launch may use 1 .. kMaxWavesPerBlock (tuning knob)
-constexpr int kMaxWavesPerBlock = 8;
+constexpr int kMaxWavesPerBlock = 4;  // (8 strips per workgroup never measured faster than 4)
 // Rows in flight per wavefront (a divisor of the unroll factor, so slots stay static).  Tuning builds override per model.
 #ifndef CRD_PREFETCH_FHN
 #define CRD_PREFETCH_FHN 4
@@ -58,6 +58,7 @@ __device__ __forceinline__ Real from_lane_above(Real x);
 template <>
 __device__ __forceinline__ double from_lane_below<double>(double x)
 {
+
 	int lo = __double2loint(x), hi = __double2hiint(x);
 	lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 	hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
@@ -66,6 +67,7 @@ __device__ __forceinline__ double from_lane_below<double>(double x)
 template <>
 __device__ __forceinline__ double from_lane_above<double>(double x)
 {
+
 	int lo = __double2loint(x), hi = __double2hiint(x);
 	lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 	hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
@@ -127,7 +129,6 @@ struct FusedArgs {
 	int xs_lanes;             // remap 2: phi-lanes of chunk sequences per strip block and XCD
 	int nchunks;              // chunks of both ranges
 	int sw;                   // wavefronts per block = adjacent strips a block covers
-	int lockstep;             // the block's wavefronts march in step (one barrier per pipeline iteration)
 	double *err_partials;     // EMBED: one weighted square sum per work item
 	Real rtol, atol;          // EMBED: error weights 1 / (rtol |y_n| + atol)
 };
@@ -202,12 +203,13 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	// scalar-cache loads into SGPRs (s_load_dwordx2), no vector registers and no vector-memory instruction
 	const __attribute__((address_space(4))) Real *const brow = (const __attribute__((address_space(4))) Real *)(s.brow);
 
-	// Row base pointers are scalar; a single slab wraps rows outside [0, nyl).
+	// Row base pointers are scalar; a single slab wraps rows outside [0, nyl).  Branch-free: this runs once per pipeline
+	// iteration in every wavefront's instruction stream (scalar work is not free: ~40 of the ~140 instructions of an iteration
+	// were scalar before the row bookkeeping was pared down).
+	const int wrap_nyl = s.wrap ? s.nyl : 0;
 	auto row_base = [&](int j) -> ptrdiff_t {
-		if (s.wrap) {
-			if (j < 0) j += s.nyl;
-			else if (j >= s.nyl) j -= s.nyl;
-		}
+		j += wrap_nyl & (j >> 31);
+		j -= (j >= s.nyl) ? wrap_nyl : 0;
 		return (ptrdiff_t)j * nx;
 	};
 	// Global phi boundary rows (src/FHNmodel_torus.cpp:643-653), also when they are recomputed as another slab's ghost rows.
@@ -221,6 +223,10 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	// Pipeline registers.  Row jbase+m of an array lives in slot m mod M (m & 1 for the two-deep v arrays), so with the
 	// loop unrolled M times every access has a compile-time slot and no value is ever moved between registers.
 	Real u0[M], v0[M], U1[M], U2[M], U3[M], V1[2], V2[2], V3[2], aU[M], aV[M];
+	// (Keeping aU / aV in LDS instead -- 90 VGPRs, five wavefronts per SIMD -- measured 3-5 % SLOWER on every grid: the twelve LDS
+	// accesses per iteration cost more than the fifth wavefront brings.)
+#define ACC_U(S) aU[S]
+#define ACC_V(S) aV[S]
 	Real U4[M], V4[2], K4U[2], K4V[2];  // EMBED: y_new window and k4 of the last two rows
 	Real err2 = (Real)0;
 #pragma unroll
@@ -243,13 +249,17 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	}
 #pragma unroll
 	for (int k = 0; k < M; k++) bq[k] = (Real)0;
+	// running scalars of the row loop: the row the next prefetch takes (the tail re-reads the last valid row instead of running
+	// past the plane) and the output rows of stage 4 (row jbase + m - 4 at iteration m)
+	int jn = (jbase + kPrefetch < jlast) ? jbase + kPrefetch : jlast;
+	Real *out_row_u = a.out_u + (ptrdiff_t)(jbase - 4) * nx, *out_row_v = a.out_v + (ptrdiff_t)(jbase - 4) * nx;
 
 	// One pipeline iteration at m == K (mod M).  GUARDED: the first iterations of a chunk, where stage k's inputs exist only
 	// from iteration 2k on.
 	auto iteration = [&](int m, auto kk, auto guarded) {
 		constexpr int K = decltype(kk)::value;
 		constexpr bool GUARDED = decltype(guarded)::value;
-		if (a.lockstep) __builtin_amdgcn_s_barrier();  // uniform over the block: its wavefronts share the chunk, hence niter
+		__builtin_amdgcn_s_barrier();  // lockstep; uniform over the block: its wavefronts share the chunk, hence niter
 		// slots of rows p, p-1, ... p-6 (with M = 4, row p-4 shares its slot with row p)
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M;
 		constexpr int S5 = (K + 2 * M - 5) % M, S6 = (K + 2 * M - 6) % M;
@@ -260,11 +270,11 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		v0[S0] = pv[P];
 		bq[S0] = uniform(pb[P]);
 		{
-			const int pn = (p + kPrefetch < jlast) ? p + kPrefetch : jlast;  // the tail re-reads a valid row instead of running past the plane
-			const ptrdiff_t rb = row_base(pn);
+			const ptrdiff_t rb = row_base(jn);
 			pu[P] = CRD_ROW_LOAD(at_lane(a.in_u + rb, xb));
 			pv[P] = CRD_ROW_LOAD(at_lane(a.in_v + rb, xb));
-			pb[P] = brow[pn];
+			pb[P] = brow[jn];
+			jn = (jn < jlast) ? jn + 1 : jlast;
 		}
 		Real du, dv;
 		// ---- stage 1, centre row p-1: y0 rows p-2, p-1, p -----------------------------------------------------
@@ -274,8 +284,8 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 			                       ABSORB && a.absorb[0] && boundary_row(c), du, dv);
 			U1[S1] = fmadd(a.h2, du, u0[S1]);
 			V1[S1 & 1] = fmadd(a.h2, dv, v0[S1]);
-			aU[S1] = fmadd(a.h6, du, u0[S1]);
-			aV[S1] = fmadd(a.h6, dv, v0[S1]);
+			ACC_U(S1) = fmadd(a.h6, du, u0[S1]);
+			ACC_V(S1) = fmadd(a.h6, dv, v0[S1]);
 		}
 		// ---- stage 2, centre row p-2: y1 rows p-3, p-2, p-1 ---------------------------------------------------
 		if (!GUARDED || m >= 4) {
@@ -284,8 +294,8 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 			                       ABSORB && a.absorb[1] && boundary_row(c), du, dv);
 			U2[S2] = fmadd(a.h2, du, u0[S2]);
 			V2[S2 & 1] = fmadd(a.h2, dv, v0[S2]);
-			aU[S2] = fmadd(a.h3, du, aU[S2]);
-			aV[S2] = fmadd(a.h3, dv, aV[S2]);
+			ACC_U(S2) = fmadd(a.h3, du, ACC_U(S2));
+			ACC_V(S2) = fmadd(a.h3, dv, ACC_V(S2));
 		}
 		// ---- stage 3, centre row p-3: y2 rows p-4, p-3, p-2 ---------------------------------------------------
 		if (!GUARDED || m >= 6) {
@@ -294,19 +304,20 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 			                       ABSORB && a.absorb[2] && boundary_row(c), du, dv);
 			U3[S3] = fmadd(a.h1, du, u0[S3]);
 			V3[S3 & 1] = fmadd(a.h1, dv, v0[S3]);
-			aU[S3] = fmadd(a.h3, du, aU[S3]);
-			aV[S3] = fmadd(a.h3, dv, aV[S3]);
+			ACC_U(S3) = fmadd(a.h3, du, ACC_U(S3));
+			ACC_V(S3) = fmadd(a.h3, dv, ACC_V(S3));
 		}
 		// ---- stage 4, centre row p-4: y3 rows p-5, p-4, p-3 -> the new state ----------------------------------
 		if (!GUARDED || m >= 8) {
 			const int c = p - 4;
 			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
 			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);
-			const Real nu = fmadd(a.h6, du, aU[S4]), nv = fmadd(a.h6, dv, aV[S4]);
-			if ((EMBED ? (c >= j0 && c < j1) : c < j1) && lane_stores) {  // without the fifth stage c >= j0 holds from iteration 8 on
-				const ptrdiff_t o = (ptrdiff_t)c * nx;
-				*at_lane(a.out_u + o, ob) = nu;
-				*at_lane(a.out_v + o, ob) = nv;
+			const Real nu = fmadd(a.h6, du, ACC_U(S4)), nv = fmadd(a.h6, dv, ACC_V(S4));
+			// Without the fifth stage rows j0 <= c < j1 are exactly iterations 8 .. niter-1; with it (one more apron row each side)
+			// the first and the last iteration of the range fall outside.
+			if ((!EMBED || (c >= j0 && c < j1)) && lane_stores) {
+				*at_lane(out_row_u, ob) = nu;
+				*at_lane(out_row_v, ob) = nv;
 			}
 			if (EMBED) {
 				U4[S4] = nu;
@@ -327,6 +338,8 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 				err2 = fmadd(eu, eu, fmadd(ev, ev, err2));
 			}
 		}
+		out_row_u += nx;
+		out_row_v += nx;
 	};
 	using std::integral_constant;
 	// guarded prologue: up to the first multiple of M at or beyond 2 * APRON, so the steady-state loop starts at slot 0
@@ -471,14 +484,12 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	// Four adjacent strips per block marching in lockstep: 0.417 ms on 8192^2 fp64 against 0.441 without the barriers and
 	// 0.4205 with one barrier per four iterations (tools/tune_fused.py, interleaved in one process; fp32 0.219 vs 0.232,
 	// Goldbeter -- instruction-bound -- unchanged); 2 or 8 strips per block lose half of the gain, 3 / 5 / 6 more.
-	int sw = kWavesPerBlock, lockstep = 1;
+	int sw = kWavesPerBlock;
 	if (const char *e = tuning_knob("CRD_FUSED_STRIPS")) {  // tuning knobs
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= kMaxWavesPerBlock) sw = v;
 	}
-	if (const char *e = tuning_knob("CRD_FUSED_LOCKSTEP")) lockstep = std::atoi(e) != 0;
 	a.sw = sw;
-	a.lockstep = lockstep;
 	a.err_partials = c.err_partials;
 	a.rtol = (Real)c.rtol;
 	a.atol = (Real)c.atol;

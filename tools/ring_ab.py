@@ -11,7 +11,7 @@ import crdmodel_amd as crd  # noqa: E402
 
 nx = int(os.environ.get("NX", "8192"))
 steps = int(os.environ.get("STEPS", "400"))
-variants = os.environ.get("RING_VARIANTS", ";CRD_FUSED_LOCKSTEP=0").split(";")
+variants = os.environ.get("RING_VARIANTS", ";CRD_FUSED_REMAP=2").split(";")
 keys = sorted({kv.split("=")[0] for v in variants for kv in v.split(",") if kv})
 for ny in [int(v) for v in os.environ.get("NYS", "1024,2048").split(",")]:
     p = crd.make_params("fhn", "torus", nx, 80.0, 20.0, 0.12, 1.25, ny=ny)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of fused-stepper variants in ONE process (guide rule: N variants x M rounds, report median/min).
-Variants are environment knobs the launch code reads on every launch: CRD_FUSED_CHUNK, CRD_FUSED_REMAP, CRD_FUSED_STRIPS, CRD_FUSED_LOCKSTEP."""
+Variants are environment knobs the launch code reads on every launch: CRD_FUSED_CHUNK, CRD_FUSED_REMAP (0 / 1 / 2), CRD_FUSED_STRIPS, CRD_FUSED_ONEROUND."""
 import os
 import statistics
 import sys
@@ -28,7 +28,7 @@ slab.step_rk4(0.0, dt, 50)
 res = {v: [] for v in variants}
 for r in range(rounds):
     for v in variants:
-        for k in ("CRD_FUSED_CHUNK", "CRD_FUSED_REMAP", "CRD_FUSED_STRIPS", "CRD_FUSED_LOCKSTEP", "CRD_FUSED_ONEROUND"):
+        for k in ("CRD_FUSED_CHUNK", "CRD_FUSED_REMAP", "CRD_FUSED_STRIPS", "CRD_FUSED_ONEROUND"):
             os.environ.pop(k, None)
         for kv in v.split(","):
             key, val = kv.split("=")
@@ -36,8 +36,6 @@ for r in range(rounds):
                 os.environ["CRD_FUSED_CHUNK"] = val
             if key == "strips":
                 os.environ["CRD_FUSED_STRIPS"] = val
-            if key == "lockstep":
-                os.environ["CRD_FUSED_LOCKSTEP"] = val
             if key == "oneround":
                 os.environ["CRD_FUSED_ONEROUND"] = val
             if key == "remap" and val != "0":
