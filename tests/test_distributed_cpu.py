@@ -71,6 +71,24 @@ def _worker(rank, world, port, result_dir):
             rows = np.arange(js - depth, je + 1 + depth) % g.ny
             assert np.array_equal(plane, y_global[rows, :, 0]), "ghost rows are not the periodic neighbours"
 
+        # --- bench.py's halo self-check, expectation side: the field every rank uploads and the rows it then expects in its
+        #     ghost rows, with the exchange itself done by the library's plan over gloo (on the GPU the library's own transport
+        #     does it: tests/test_gpu_parity.py runs the whole check on the self-ring) ---------------------------------------
+        import bench
+
+        for dtype in (np.float64, np.float32):
+            for depth in (1, 16):  # (every slab of this grid has at least 16 rows; all ranks must use one depth)
+                bad = 0
+                for var in (0, 1):
+                    plane = np.full((nyl + 2 * depth, nx), np.nan, dtype=dtype)
+                    plane[depth:depth + nyl] = bench.selfcheck_pattern(np.arange(js, je + 1), nx, var, dtype)
+                    _exchange(dist, plane, nyl, depth, rank, world, crd)
+                    lo_rows, hi_rows = bench.selfcheck_ghost_rows(js, je, g.ny, depth)
+                    bad += int(np.count_nonzero(plane[:depth] != bench.selfcheck_pattern(lo_rows, nx, var, dtype)))
+                    bad += int(np.count_nonzero(plane[depth + nyl:] != bench.selfcheck_pattern(hi_rows, nx, var, dtype)))
+                    assert len(np.unique(plane)) > nyl  # the field tells rows and columns apart
+                assert bad == 0, "self-check expectation does not match what the ring delivers"
+
         # --- f() on the slab with exchanged strips == rows of the whole-domain f() -------------------------------
         def slab_rhs(t, y_local):
             plane = np.empty((nyl + 2, nx))
