@@ -17,6 +17,7 @@
 // same reason in phi (rows come from the slab's ghost rows, or wrap for a single slab).
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -419,12 +420,14 @@ int resident_wavefronts()
 }
 
 template <typename Real, int MODEL>
-int fused_chunk_rows(int nstrips, int rows, bool one_round)
+int fused_chunk_rows(int nstrips, int rows, int chunk_mode)  // 0: 32 rows, 1: one round, 2: 64 rows
 {
+	bool one_round = chunk_mode == 1;
 	const int slots = resident_wavefronts<Real, MODEL>();
 	int chunk = 32;
 	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
 	if (const char *e = tuning_knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
+	if (chunk_mode == 2 && chunk == 32 && (long)nstrips * ((rows + 63) / 64) >= 2L * slots) chunk = 64;  // fewer apron rows recomputed: pays where fp64 issue binds (Goldbeter)
 	if (one_round) {
 		const long strip_blocks = (nstrips + kWavesPerBlock - 1) / kWavesPerBlock, fit = (slots / kWavesPerBlock) / strip_blocks;
 		const long need = fit >= 1 ? (rows + fit - 1) / fit : 0;
@@ -448,9 +451,9 @@ int fused_chunk_rows(int nstrips, int rows, bool one_round)
 // MI355X of the same pool, mapping 2 -4.4 % on a fourth; one-round chunks -10 % (4096 x 1024) to +2 % (16384 x 2048 fp32) --
 // hence measured at run time, on the device and the shape at hand.  Every candidate computes bit-identical results.
 struct PlanCandidate {
-	int one_round, remap;
+	int one_round, remap;  // one_round: the chunk mode -- 0 = 32 rows, 1 = stretched to one round, 2 = 64 rows
 };
-constexpr PlanCandidate kPlanCandidates[] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {1, 1}};
+constexpr PlanCandidate kPlanCandidates[] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {1, 1}, {2, 0}, {2, 1}};
 
 template <typename Real, int MODEL>
 hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, int js, int ny,
@@ -499,7 +502,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const dim3 block(kLanes * sw);
 
 	auto configure = [&](int one_round, int remap) {
-		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round != 0);
+		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round);
 		a.nchunks1 = (rows + a.chunk - 1) / a.chunk;
 		a.nchunks = a.nchunks1 + (rows2 + a.chunk - 1) / a.chunk;
 		a.nitems = a.nstrips * a.nchunks;
@@ -540,40 +543,55 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		hipError_t err = hipEventCreate(&e0);
 		if (err == hipSuccess) err = hipEventCreate(&e1);
-		float best = 0.f, base = 0.f;
-		int best_k = 0, reps = 3;
-		for (int k = 0; err == hipSuccess && k < (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]); k++) {
+		// Candidates are timed round-robin, kRounds times, and each keeps its best round: a device's clock drifts while the
+		// measurement runs (a Goldbeter launch sequence lost 15 % over five candidates timed one after the other), and a
+		// candidate must not win or lose by its place in the queue.
+		constexpr int kCandidates = (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]), kRounds = 3;
+		float t_best[kCandidates];
+		bool live[kCandidates];
+		int reps = 3;
+		for (int k = 0; k < kCandidates; k++) {
+			t_best[k] = 0.f;
 			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap);
-			if (kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, false)) continue;  // same as the 32-row plan
-			float ms = 0.f;
-			for (int pass = 0; pass < 2 && err == hipSuccess; pass++) {
-				err = fire();  // warm-up of this variant
-				if (err == hipSuccess) err = hipEventRecord(e0, st);
-				for (int r = 0; err == hipSuccess && r < reps; r++) err = fire();
-				if (err == hipSuccess) err = hipEventRecord(e1, st);
-				if (err == hipSuccess) err = hipEventSynchronize(e1);
-				if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
-				if (k > 0 || reps > 3 || ms >= 1.0f || ms <= 0.f) break;
-				reps = (int)(3.0f / ms) + 1 < 30 ? (int)(3.0f / ms) + 1 : 30;  // short launches: time about a millisecond's worth, then again
-			}
-			if (err != hipSuccess) break;
-			ms *= 3.0f / (float)reps;  // per three launches, whatever the repetition count
-			if (k == 0) base = best = ms;
-			else if (ms < best) {
-				best = ms;
-				best_k = k;
-			}
+			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0)) ;  // (same as a 32-row plan)
+			if (live[k] && kPlanCandidates[k].remap != a.remap) live[k] = false;  // (the mapping fell back to dispatch order)
 		}
+		for (int round = 0; round < kRounds && err == hipSuccess; round++)
+			for (int k = 0; err == hipSuccess && k < kCandidates; k++) {
+				if (!live[k]) continue;
+				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap);
+				float ms = 0.f;
+				for (int pass = 0; pass < 2 && err == hipSuccess; pass++) {
+					err = fire();  // warm-up of this variant
+					if (err == hipSuccess) err = hipEventRecord(e0, st);
+					for (int r = 0; err == hipSuccess && r < reps; r++) err = fire();
+					if (err == hipSuccess) err = hipEventRecord(e1, st);
+					if (err == hipSuccess) err = hipEventSynchronize(e1);
+					if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+					if (round > 0 || k > 0 || reps > 3 || ms >= 4.0f || ms <= 0.f) break;
+					reps = (int)(12.0f / ms) + 1 < 40 ? (int)(12.0f / ms) + 1 : 40;  // time about four milliseconds' worth per candidate and round, then again
+				}
+				if (err != hipSuccess) break;
+				ms /= (float)reps;
+				if (std::getenv("CRD_AUTOTUNE_VERBOSE"))
+					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d: %.4f ms per launch (%d launches timed)\n", d.nx, rows,
+					             round, kPlanCandidates[k].one_round, a.chunk, a.remap, ms, reps);
+				if (t_best[k] == 0.f || ms < t_best[k]) t_best[k] = ms;
+			}
+		int best_k = 0;
+		for (int k = 1; k < kCandidates; k++)
+			if (live[k] && t_best[k] > 0.f && t_best[k] < t_best[best_k]) best_k = k;
+		const float base = t_best[0], best = t_best[best_k];
 		if (e0) (void)hipEventDestroy(e0);
 		if (e1) (void)hipEventDestroy(e1);
 		if (err != hipSuccess) return err;
-		if (best > 0.99f * base) best_k = 0;  // a candidate has to beat the plain plan by more than timing noise
+		if (best > 0.985f * base) best_k = 0;  // a candidate has to beat the plain plan by more than timing noise
 		plan->tuned = 1;
 		plan->one_round = kPlanCandidates[best_k].one_round;
 		plan->remap = kPlanCandidates[best_k].remap;
 		plan->rows = rows;
-		plan->ms_default = base / 3.f;
-		plan->ms_best = best / 3.f;
+		plan->ms_default = base;
+		plan->ms_best = best_k ? best : base;
 	}
 	const bool use_plan = plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows;
 	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0);

@@ -306,7 +306,7 @@ const char *crd_dominant_kernel_name(const crd_ctx *ctx);
 typedef struct crd_launch_plan {
 	int32_t autotune;     /* measuring enabled */
 	int32_t tuned;        /* a measurement has been made */
-	int32_t one_round;    /* chunks stretched so that all workgroups are resident at once */
+	int32_t one_round;    /* chunk mode: 0 = 32-row chunks, 1 = stretched so that all workgroups are resident at once, 2 = 64-row chunks */
 	int32_t xcd_mapping;  /* 0 theta-first dispatch order, 1 one contiguous band of the slab per XCD, 2 the same with succession in phi */
 	int32_t rows;         /* height of the launch it was measured on */
 	int32_t reserved;
