@@ -144,6 +144,7 @@ _SIGNATURES = {
     "crd_state_max_abs": (C.c_int, [_vp, C.POINTER(C.c_double)]),
     "crd_set_autotune": (C.c_int, [_vp, C.c_int]),
     "crd_get_launch_plan": (C.c_int, [_vp, C.POINTER(LaunchPlan)]),
+    "crd_plan_launches": (C.c_int, [_vp]),
 }
 
 _lib = None

@@ -600,6 +600,21 @@ int crd_group_integrate_adaptive(crd_ctx *const *ctxs, int n, double t0, double 
 	return integrate_adaptive_impl(ctxs, n, t0, tout, opt, stats);
 }
 
+int crd_plan_launches(crd_ctx *c)
+{
+	if (!c) return CRD_EINVAL;
+	if (resolve_stepper(c) != CRD_STEPPER_FUSED || c->plan.tuned || !c->plan.autotune) return CRD_OK;
+	if (int rc = set_device(c)) return rc;
+	// One step of the resident state into the scratch planes, discarded: its first launch is where the plan is measured.  The
+	// state itself (plane Y) is only read; ghost rows may be stale, which only matters to results nobody keeps.
+	FusedCall call = make_fused_call(c, 0.0, 1e-9 * crd_stable_dt(&c->p), crd_ctx::Y, crd_ctx::SA);
+	for (int k = 0; k < 4; k++) call.absorb[k] = 0;
+	const int lo = c->halo == CRD_HALO_SELF ? 0 : kStepHalo, hi = c->halo == CRD_HALO_SELF ? c->nyl : c->nyl - kStepHalo;
+	HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, lo, hi, 0, 0, c->compute));
+	HIP_TRY(c, hipStreamSynchronize(c->compute));
+	return CRD_OK;
+}
+
 int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double *ms_total, double *kernel_ms, int *launches_per_step)
 {
 	if (!c) return CRD_EINVAL;

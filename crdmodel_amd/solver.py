@@ -244,6 +244,10 @@ class Slab:
     def set_autotune(self, on):
         self._check(lib().crd_set_autotune(self._h, 1 if on else 0), "crd_set_autotune")
 
+    def plan_launches(self):
+        """Measure the fused step kernel's launch plan now (state not advanced) rather than inside the first step_rk4."""
+        self._check(lib().crd_plan_launches(self._h), "crd_plan_launches")
+
     def launch_plan(self):
         """The fused step kernel's launch plan as a dict (crd_launch_plan)."""
         lp = capi.LaunchPlan()
