@@ -59,8 +59,15 @@ int ensure_staging(crd_ctx *c, size_t bytes)
 int resolve_stepper(const crd_ctx *c)
 {
 	if (c->stepper == CRD_STEPPER_STAGED) return CRD_STEPPER_STAGED;
-	// the deep-halo exchange of a multi-slab run sends kGhost owned rows: shorter slabs step with the staged kernels
-	const bool can_fuse = fused_step_supported(c->p.precision, c->desc) && (c->halo == CRD_HALO_SELF || c->nyl >= kGhost);
+	// The deep-halo exchange of a multi-slab run sends kGhost owned rows: shorter slabs step with the staged kernels -- and
+	// since every slab of a run must take the same stepper, the SHORTEST slab of the run decides (each context, and each
+	// rank of an RCCL run, works that out for itself from the slab formula).
+	int64_t shortest = c->nyl;
+	for (int k = 0; c->n_slabs > 1 && k < c->n_slabs; k++) {
+		int64_t js, je;
+		if (crd_slab_extents(c->g.ny, k, c->n_slabs, &js, &je) == CRD_OK) shortest = std::min<int64_t>(shortest, je - js + 1);
+	}
+	const bool can_fuse = fused_step_supported(c->p.precision, c->desc) && (c->halo == CRD_HALO_SELF || shortest >= kGhost);
 	if (c->stepper == CRD_STEPPER_FUSED) return can_fuse ? CRD_STEPPER_FUSED : -1;
 	return can_fuse ? CRD_STEPPER_FUSED : CRD_STEPPER_STAGED;
 }
