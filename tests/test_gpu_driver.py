@@ -170,3 +170,72 @@ def test_driver_binary_side_channel(gpu_device, tmp_path):
         assert os.path.getsize(only / ("FHNmodel_torus_u.%03d.txt" % k)) == 0
     run = post.load_run(str(only), "fhn", "torus")
     assert np.array_equal(run.fields["u"], u_text)
+
+
+def test_seeded_sweep_of_driver_runs(gpu_device, tmp_path):
+    """Twelve seeded random runs through the four reference-named executables and `crd_run`: random parameters, mesh keys
+    as each program spells them, includeAllVars, varyBeta / justDiffusion, number of GPUs (slabs on this one device), stepper,
+    with and without the binary side-channel -- files read back the way the plot scripts read them and compared with the
+    oracle's fixed-step trajectory at the output times."""
+    rng = np.random.default_rng(1248)
+    for case in range(12):
+        model = ("fhn", "goldbeter")[int(rng.integers(2))]
+        surface = ("torus", "flat")[int(rng.integers(2))]
+        nx, ny = int(rng.integers(12, 60)), int(rng.integers(40, 120))
+        vary = int(rng.integers(2)) if model == "fhn" else 0
+        jd = int(model == "goldbeter" and rng.integers(3) == 0)
+        all_vars = int(rng.integers(2))
+        beta = float(rng.uniform(0.9, 1.5)) if model == "fhn" else float(rng.uniform(0.2, 0.9))
+        L, W, D = float(rng.uniform(40, 100)), float(rng.uniform(10, 25)), float(rng.uniform(0.05, 0.2))
+        nt = int(rng.integers(1, 5))
+        wl, ww, inside = float(rng.uniform(0.05, 0.3)), float(rng.uniform(0.2, 0.8)), int(rng.integers(2))
+        p = crd.make_params(model, surface, nx, L, W, D, beta, ny=ny, vary_beta=vary, beta_min=0.7, beta_max=1.7, just_diffusion=jd)
+        dt = float(rng.uniform(0.4, 0.8)) * crd.stable_dt(p)
+        t_final = nt * int(rng.integers(5, 16)) * dt
+        t_b = float(rng.uniform(0, 1.2)) * t_final
+        mesh_key = "thetaMesh" if model == "fhn" else "xMesh"
+        d = tmp_path / ("case%02d" % case)
+        d.mkdir()
+        ini = d / "run.ini"
+        ini.write_text("[Parameters]\ndiffusion = %r\nbeta = %r\nsurfaceWidth = %r\nsurfaceLength = %r\nwaveLength = %r\nwaveWidth = %r\nwaveInside = %d\n"
+                       "outputTimestep = %d\ntBoundary = %r\ntFinal = %r\n%s = %d\nphiMesh = %d\nbetaMin = 0.7\nbetaMax = 1.7\n\n[System]\nincludeAllVars = %d\n"
+                       "varyBeta = %d\njustDiffusion = %d\nicType = 0\n[Solver]\ndt = %r\n" % (D, beta, W, L, wl, ww, inside, nt, t_b, t_final, mesh_key, nx, ny, all_vars,
+                                                                                      vary, jd, dt))
+        gpus = int(rng.integers(1, 4))
+        if ny // gpus < 8:
+            gpus = 1
+        alias = {("fhn", "torus"): "FHNmodel_torus", ("fhn", "flat"): "FHNmodel_flat", ("goldbeter", "torus"): "GoldbeterModel_torus",
+                 ("goldbeter", "flat"): "GoldbeterModel_flat"}[(model, surface)]
+        binary = bool(rng.integers(2))
+        if gpus == 1 and not binary and rng.integers(2):
+            cmd = [os.path.join(BIN, alias), str(ini)]  # the reference's own command line
+        else:
+            cmd = [os.path.join(BIN, "crd_run"), "--model", model, "--surface", surface, "--gpus", str(gpus), "--devices", "1", "--quiet",
+                   "--stepper", ("auto", "staged")[int(rng.integers(2))]] + (["--binary"] if binary else []) + [str(ini)]
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (case, cmd, r.stderr)
+        cfg = crd.load_ini(ini, model, surface)
+        pp = cfg.params
+        op = co.make_problem(co.FHN if model == "fhn" else co.GOLDBETER, co.TORUS if surface == "torus" else co.FLAT, nx, L, W, D, beta, ny=ny,
+                             vary_beta=vary, beta_min=0.7, beta_max=1.7, just_diffusion=jd, t_boundary=pp.t_boundary)
+        y = crd.initial_conditions(cfg)
+        frames = [y]
+        d_tout = cfg.t_final / nt
+        steps = int(np.ceil(d_tout / cfg.dt - 1e-12))
+        for k in range(nt):
+            y = co.rk4(op, y, k * d_tout, d_tout / steps, steps)
+            frames.append(y)
+        want = np.stack(frames)
+        prefix = alias
+        names = ("u", "v") if model == "fhn" else ("Z", "Y")
+        got0, meta = load_like_the_plot_script(d, prefix, names[0])
+        assert meta["nprocs"] == gpus and got0.shape == want[..., 0].shape, (case, meta)
+        assert rel_err(got0, want[..., 0]) <= 1e-9, (case, cmd)
+        if all_vars:
+            got1, _ = load_like_the_plot_script(d, prefix, names[1])
+            assert rel_err(got1, want[..., 1]) <= 1e-9 or float(np.max(np.abs(want[..., 1]))) == 0.0, (case, cmd)
+        else:
+            assert all(os.path.getsize(d / ("%s_%s.%03d.txt" % (prefix, names[1], k))) == 0 for k in range(gpus))
+        if binary:
+            run = post.load_run(str(d), model, surface, include_all_vars=bool(all_vars))
+            assert np.array_equal(run.fields[names[0]], got0)
