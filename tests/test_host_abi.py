@@ -240,3 +240,53 @@ def test_arkrhsfn_shim_compiles_as_c(tmp_path):
            "-o", str(tmp_path / "shim"), "-L", lib_dir, "-lcrd", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_seeded_sweep_of_host_side_rules_against_the_oracle():
+    """300 seeded random parameter sets through the host-only entry points, each against the oracle's restatement: geometry
+    scalars (incl. the `(long)(nx * R / r)` truncation and the flat `nx * (long)(L / W)` rule), slab extents that tile the
+    grid, the halo plan's pairing, and the initial-condition rules of the four programs on random row ranges."""
+    rng = np.random.default_rng(77)
+    for case in range(300):
+        model = ("fhn", "goldbeter")[int(rng.integers(2))]
+        surface = ("torus", "flat")[int(rng.integers(2))]
+        nx = int(rng.integers(4, 90))
+        W = float(rng.choice([10.0, 20.0, 12.5, 7.0]))
+        L = W * float(rng.choice([1.0, 2.0, 4.0, 5.0, 3.5, 2.2]))
+        if surface == "torus" and L <= W * 1.01:
+            L = 2.0 * W  # R = r is a singular (horn) torus
+        beta = float(rng.uniform(0.8, 1.6)) if model == "fhn" else float(rng.uniform(0.2, 0.9))
+        vary = int(rng.integers(2))
+        ny_override = 0 if rng.integers(3) else int(rng.integers(8, 70))
+        p = crd.make_params(model, surface, nx, L, W, 0.12, beta, ny=ny_override, vary_beta=vary, beta_min=0.7, beta_max=1.7)
+        op = co.make_problem(co.FHN if model == "fhn" else co.GOLDBETER, co.TORUS if surface == "torus" else co.FLAT, nx, L, W, 0.12, beta, ny=ny_override,
+                             vary_beta=vary, beta_min=0.7, beta_max=1.7)
+        g = crd.grid_of(p)
+        assert (g.nx, g.ny, g.dx, g.dy) == (op.nx, op.ny, op.dx, op.dy), (case, model, surface, nx, L, W)
+        if g.ny < 8:
+            continue
+        # slabs tile the grid; the plan pairs every send with the matching receive of the neighbour
+        n = int(rng.integers(1, min(6, g.ny // 2) + 1))
+        ext = [crd.slab_extents(g.ny, k, n) for k in range(n)]
+        assert ext[0][0] == 0 and ext[-1][1] == g.ny - 1 and all(ext[k][1] + 1 == ext[k + 1][0] for k in range(n - 1))
+        depth = 1
+        plans = [crd.halo_plan(k, n, ext[k][1] - ext[k][0] + 1, depth) for k in range(n)]
+        for k in range(n):
+            for is_send, peer, row_begin, _ in plans[k]:
+                if is_send:  # every send has a receive from this slab waiting in the peer's plan
+                    assert [q for q in plans[peer] if not q[0] and q[1] == k], (case, k, peer)
+        # initial conditions on a random row range
+        ic_type = int(rng.integers(3))
+        cfg = crd.run_config(p, wave_length=float(rng.uniform(0.05, 0.4)), wave_width=float(rng.uniform(0.1, 0.9)), wave_inside=int(rng.integers(2)),
+                             ic_type=ic_type)
+        j0 = int(rng.integers(0, g.ny))
+        j1 = int(rng.integers(j0, g.ny))
+        got = crd.initial_conditions(cfg, j0, j1)  # every combination here is one a reference program runs: none may be refused
+        want = co.initial_conditions(op, cfg.wave_length, cfg.wave_width, cfg.wave_inside, ic_type, steady_state=crd.steady_state(model, beta))
+        if model == "goldbeter" and vary == 1 and ic_type == 2:
+            # the random rule draws from rand() row by row from the FIRST row of the call (every reference rank seeds alike)
+            assert got.shape == (j1 - j0 + 1, g.nx, 2) and np.all((got >= 0) & (got <= 1.4 + 1e-12))
+            if j0 == 0:
+                assert np.array_equal(got, want[: j1 + 1]), case
+        else:
+            assert np.array_equal(got, want[j0:j1 + 1]), (case, model, surface, vary, ic_type)
