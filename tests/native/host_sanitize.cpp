@@ -56,6 +56,49 @@ int main(int argc, char **argv)
 	CHECK(crd_config_load_ini((dir + "/empty.ini").c_str(), CRD_MODEL_FHN, CRD_SURFACE_FLAT, &cfg, err, sizeof err) != CRD_OK);
 	CHECK(crd_config_load_ini(nullptr, CRD_MODEL_FHN, CRD_SURFACE_FLAT, &cfg, err, sizeof err) != CRD_OK);
 
+	// ---- ini reader under mutation: 3000 seeded random edits of the good file (bytes replaced, lines cut, duplicated, truncated);
+	//      any status is fine, a crash or a sanitizer report is not; whatever it accepts must describe a sane run
+	{
+		std::string base;
+		{
+			FILE *f = std::fopen(good.c_str(), "r");
+			CHECK(f);
+			char buf[4096];
+			const size_t k = std::fread(buf, 1, sizeof buf, f);
+			std::fclose(f);
+			base.assign(buf, k);
+		}
+		unsigned long long s = 0x9E3779B97F4A7C15ull;
+		auto rnd = [&]() { s ^= s << 13; s ^= s >> 7; s ^= s << 17; return s; };
+		const char alphabet[] = "=[]\n\t ;#.-+eE0123456789abcxyzParametersSystemSolver\0\xff";
+		int accepted = 0;
+		for (int it = 0; it < 3000; it++) {
+			std::string t = base;
+			const int edits = 1 + (int)(rnd() % 4);
+			for (int e = 0; e < edits && !t.empty(); e++) {
+				const size_t at = rnd() % t.size();
+				switch (rnd() % 5) {
+				case 0: t[at] = alphabet[rnd() % (sizeof alphabet - 1)]; break;
+				case 1: t.erase(at, 1 + rnd() % 12); break;
+				case 2: t.insert(at, t.substr(rnd() % t.size(), rnd() % 40)); break;
+				case 3: t.resize(at); break;
+				default: t.insert(at, 1, alphabet[rnd() % (sizeof alphabet - 1)]); break;
+				}
+			}
+			write_file(dir + "/mut.ini", t);
+			crd_run_config c;
+			char e2[64];
+			const int model = (int)(rnd() % 2), surface = (int)(rnd() % 2);
+			if (crd_config_load_ini((dir + "/mut.ini").c_str(), model, surface, &c, e2, sizeof e2) == CRD_OK) {
+				accepted++;
+				crd_grid gg;
+				CHECK(crd_grid_from_params(&c.params, &gg) == CRD_OK && gg.nx >= 2 && gg.ny >= 2 && c.output_timestep >= 1 && c.t_final > 0.0);
+			}
+			CHECK(std::strlen(e2) < sizeof e2);
+		}
+		CHECK(accepted > 0 && accepted < 3000);
+	}
+
 	// ---- geometry, slabs, plans
 	CHECK(crd_config_load_ini(good.c_str(), CRD_MODEL_FHN, CRD_SURFACE_TORUS, &cfg, err, sizeof err) == CRD_OK);
 	crd_grid g;
