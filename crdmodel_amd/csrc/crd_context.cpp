@@ -254,7 +254,10 @@ int crd_comm_attach_local(crd_ctx *const *ctxs, int n)
 		if (c->p.precision != ctxs[0]->p.precision || c->nx != ctxs[0]->nx) return fail(ctxs[0], CRD_EINVAL, "contexts of one run must share nx and precision");
 		c->group.assign(ctxs, ctxs + n);
 		c->halo = CRD_HALO_LOCAL;
-		for (int j = 0; j < k; j++)
+		// (experiment knob CRD_GROUP_OWN_STREAMS=1: every slab keeps its own streams also on a shared device, so that one slab's
+		// launch can fill the chip while another's drains)
+		static const bool own_streams = std::getenv("CRD_GROUP_OWN_STREAMS") && std::atoi(std::getenv("CRD_GROUP_OWN_STREAMS")) != 0;
+		for (int j = 0; j < k && !own_streams; j++)
 			if (ctxs[j]->device == c->device) {  // slabs on one device run on one set of streams
 				if (hipSetDevice(c->device) != hipSuccess) return fail(ctxs[0], CRD_EHIP, "hipSetDevice failed");
 				for (hipStream_t s : {c->compute, c->comm, c->band})
