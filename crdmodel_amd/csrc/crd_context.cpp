@@ -342,10 +342,12 @@ int crd_halo_exchange(crd_ctx *c, int depth)
 		return CRD_OK;
 	}
 	crd_ctx *one[1] = {c};
+	c->cycle_pos = -1;
 	if (int rc = prime_halo(one, 1, crd_ctx::Y, depth, true)) return rc;
 	HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
 	HIP_TRY(c, hipStreamSynchronize(c->comm));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));
+	if (depth == kGhost) c->cycle_pos = 0;  // a full deep-halo exchange: the fused stepper may start its cycle from here
 	return CRD_OK;
 }
 
@@ -368,6 +370,7 @@ int crd_state_upload(crd_ctx *c, const void *y, int host_is_f64)
 	const size_t bytes = 2 * (size_t)c->nx * (size_t)c->nyl * (host_is_f64 ? 8 : 4);
 	if (int rc = ensure_staging(c, 2 * (size_t)c->nx * (size_t)c->nyl * 8)) return rc;
 	c->dense.pending = false;  // a new state: nothing to resume
+	c->cycle_pos = -1;         // ... and ghost rows that belong to the old one
 	HIP_TRY(c, hipMemcpyAsync(c->stage_in, y, bytes, hipMemcpyHostToDevice, c->compute));
 	HIP_TRY(c, launch_aos_to_planes(c->p.precision, host_is_f64, c->stage_in, c->planes(crd_ctx::Y), c->nx, c->nyl, c->compute));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));

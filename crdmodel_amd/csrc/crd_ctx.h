@@ -136,6 +136,13 @@ struct crd_ctx {
 		double t_out = 0.0, t_n = 0.0, t_np1 = 0.0;
 	} dense;
 
+	// Multi-slab fused stepping: position in the deep-halo exchange cycle the resident state is at (steps taken since the ghost
+	// rows were last exchanged, 0 = just exchanged), or -1 when the ghost rows cannot be trusted (new state, another stepper,
+	// an error): crd_step_rk4 then starts with an exchange, otherwise it carries on where the previous call stopped.
+	int cycle_pos = -1;
+	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
+	int cycle_start = -1;  // the decision for the call in progress, taken for ALL slabs of the run before any thread issues (run_steps)
+
 	crd::SlabDesc desc{};
 	int stepper = CRD_STEPPER_AUTO;
 	crd::FusedPlan plan{}, plan_embed{};  // launch plans of the one-launch step (plain / with the embedded error estimate)
@@ -180,5 +187,6 @@ int prime_halo(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_
 // crd_steppers.cpp
 FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int dst);
 int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, int *timed_launches);
+void decide_cycle_start(crd_ctx *const *all, int n_all);  // call once per stepping call, before run_steps (and before any issuing thread starts)
 
 }  // namespace crd
