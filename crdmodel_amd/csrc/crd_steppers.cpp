@@ -630,8 +630,9 @@ int crd_group_integrate_adaptive(crd_ctx *const *ctxs, int n, double t0, double 
 int crd_plan_launches(crd_ctx *c)
 {
 	if (!c) return CRD_EINVAL;
-	if (resolve_stepper(c) != CRD_STEPPER_FUSED || c->plan.tuned || !c->plan.autotune) return CRD_OK;
 	if (int rc = set_device(c)) return rc;
+	if (int rc = ensure_timing_events(c)) return rc;  // (a first crd_step_rk4_timed would otherwise create its 128 events inside the region it times)
+	if (resolve_stepper(c) != CRD_STEPPER_FUSED || c->plan.tuned || !c->plan.autotune) return CRD_OK;
 	// One step of the resident state into the scratch planes, discarded: its first launch is where the plan is measured.  The
 	// state itself (plane Y) is only read; ghost rows may be stale, which only matters to results nobody keeps.
 	FusedCall call = make_fused_call(c, 0.0, 1e-9 * crd_stable_dt(&c->p), crd_ctx::Y, crd_ctx::SA);
