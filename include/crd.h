@@ -315,7 +315,8 @@ typedef struct crd_launch_plan {
 int crd_set_autotune(crd_ctx *ctx, int on);
 int crd_get_launch_plan(const crd_ctx *ctx, crd_launch_plan *out);
 /* Measure the plan NOW (a step of the resident state into scratch planes, discarded; the state is not advanced) instead of
- * inside the first crd_step_rk4 -- for callers that time their first steps.  No-op when a plan exists or autotuning is off. */
+ * inside the first crd_step_rk4 -- for callers that time their first steps; also creates the events crd_step_rk4_timed uses.  The
+ * measurement is skipped when a plan exists or autotuning is off. */
 int crd_plan_launches(crd_ctx *ctx);
 
 /* max |var0| over the slab (blow-up guard; synchronises). */
