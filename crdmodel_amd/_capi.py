@@ -79,7 +79,7 @@ class RunConfig(C.Structure):
         ("include_all_vars", C.c_int32), ("ic_type", C.c_int32),
         ("dt", C.c_double), ("dt_safety", C.c_double),
         ("n_gpus", C.c_int32), ("stepper", C.c_int32),
-        ("adaptive", C.c_int32), ("reserved", C.c_int32),
+        ("adaptive", C.c_int32), ("steady_state_decimals", C.c_int32),
         ("rtol", C.c_double), ("atol", C.c_double),
     ]
 
@@ -91,6 +91,13 @@ class LaunchPlan(C.Structure):
                 ("reserved", C.c_int32), ("ms_default", C.c_double), ("ms_chosen", C.c_double)]
 
 
+class StepTiming(C.Structure):
+    """crd_step_timing"""
+
+    _fields_ = [("ms_total", C.c_double), ("kernel_ms", C.c_double), ("exposed_halo_ms", C.c_double), ("exchange_ms", C.c_double),
+                ("steps", C.c_int64), ("halo_waits", C.c_int32), ("exchanges", C.c_int32), ("agreement_restarts", C.c_int64)]
+
+
 # name -> (restype, argtypes); the test suite checks this table against include/crd.h symbol by symbol.
 _vp = C.c_void_p
 _SIGNATURES = {
@@ -100,6 +107,7 @@ _SIGNATURES = {
     "crd_grid_from_params": (C.c_int, [C.POINTER(Params), C.POINTER(Grid)]),
     "crd_slab_extents": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "crd_steady_state": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
+    "crd_steady_state_as_printed": (C.c_int, [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "crd_initial_conditions": (C.c_int, [C.POINTER(RunConfig), C.c_int64, C.c_int64, _vp]),
     "crd_stable_dt": (C.c_double, [C.POINTER(Params)]),
     "crd_writer_open": (C.c_int, [C.POINTER(RunConfig), C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -121,6 +129,8 @@ _SIGNATURES = {
     "crd_halo_exchange": (C.c_int, [_vp, C.c_int]),
     "crd_state_download_rows": (C.c_int, [_vp, C.c_int, C.c_int64, C.c_int64, _vp]),
     "crd_halo_plan": (C.c_int, [C.c_int, C.c_int, C.c_int64, C.c_int, C.POINTER(HaloOp)]),
+    "crd_cycle_vote": (C.c_int, [C.c_int, C.POINTER(C.c_double)]),
+    "crd_cycle_agreed": (C.c_int, [C.POINTER(C.c_double)]),
     "crd_state_upload": (C.c_int, [_vp, _vp, C.c_int]),
     "crd_state_download": (C.c_int, [_vp, _vp, C.c_int]),
     "crd_host_alloc": (_vp, [C.c_size_t]),
@@ -142,9 +152,13 @@ _SIGNATURES = {
     "crd_dominant_kernel_rows": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     "crd_dominant_kernel_name": (C.c_char_p, [_vp]),
     "crd_state_max_abs": (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    "crd_trace_range_push": (None, [C.c_char_p]),
+    "crd_trace_range_pop": (None, []),
     "crd_set_autotune": (C.c_int, [_vp, C.c_int]),
     "crd_get_launch_plan": (C.c_int, [_vp, C.POINTER(LaunchPlan)]),
     "crd_plan_launches": (C.c_int, [_vp]),
+    "crd_set_diagnostics": (C.c_int, [_vp, C.c_int]),
+    "crd_get_step_timing": (C.c_int, [_vp, C.POINTER(StepTiming)]),
 }
 
 _lib = None
@@ -191,7 +205,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.crd_abi_version() != 2:
+        if L.crd_abi_version() != 3:
             raise ImportError("libcrd.so ABI version mismatch")
         _lib = L
     return _lib

@@ -213,6 +213,10 @@ void crd_destroy(crd_ctx *c)
 	                (void *)c->err_partials})
 		if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
+	for (hipEvent_t e : c->ev_diag) (void)hipEventDestroy(e);
+	if (c->ev_agree) (void)hipEventDestroy(c->ev_agree);
+	if (c->agree_dev) (void)hipFree(c->agree_dev);
+	if (c->agree_host) (void)hipHostFree(c->agree_host);
 	for (hipEvent_t e : c->ev_band) (void)hipEventDestroy(e);
 	if (c->down) {
 		(void)hipStreamSynchronize(c->down);
@@ -366,6 +370,7 @@ int crd_state_upload(crd_ctx *c, const void *y, int host_is_f64)
 {
 	if (!c || !y) return CRD_EINVAL;
 	if (c->p.precision == CRD_PRECISION_F64 && !host_is_f64) return fail(c, CRD_EINVAL, "an fp64 context takes double host buffers");
+	TraceRange range("crd_state_upload");
 	if (int rc = set_device(c)) return rc;
 	const size_t bytes = 2 * (size_t)c->nx * (size_t)c->nyl * (host_is_f64 ? 8 : 4);
 	if (int rc = ensure_staging(c, 2 * (size_t)c->nx * (size_t)c->nyl * 8)) return rc;
@@ -381,6 +386,7 @@ int crd_state_download(crd_ctx *c, void *y, int host_is_f64)
 {
 	if (!c || !y) return CRD_EINVAL;
 	if (c->p.precision == CRD_PRECISION_F64 && !host_is_f64) return fail(c, CRD_EINVAL, "an fp64 context fills double host buffers");
+	TraceRange range("crd_state_download");
 	if (int rc = set_device(c)) return rc;
 	const size_t bytes = 2 * (size_t)c->nx * (size_t)c->nyl * (host_is_f64 ? 8 : 4);
 	if (int rc = ensure_staging(c, 2 * (size_t)c->nx * (size_t)c->nyl * 8)) return rc;

@@ -142,6 +142,22 @@ struct crd_ctx {
 	int cycle_pos = -1;
 	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
 	int cycle_start = -1;  // the decision for the call in progress, taken for ALL slabs of the run before any thread issues (run_steps)
+	// RCCL runs: the ranks AGREE on the cycle position at the start of every stepping call (one 2-value ncclAllReduce(min) of
+	// (pos, -pos) on the comm stream, overlapped with the call's first step where that step involves no exchange): a rank whose
+	// state is new -- an upload on that rank only, a failed call -- makes every rank start afresh with an exchange instead of
+	// leaving the ring's send / receive sequences unpaired.
+	double *agree_dev = nullptr;   // 2 doubles on the device
+	double *agree_host = nullptr;  // 4 doubles, page-locked: [0..1] what this rank contributes, [2..3] the reduced values
+	hipEvent_t ev_agree = nullptr;
+	int64_t agreement_restarts = 0;  // calls that started afresh because the ranks disagreed (diagnostics)
+
+	// Diagnostics of a timed multi-slab fused run (crd_set_diagnostics): per exchange of the timed call, event pairs around the
+	// compute stream's wait for the halo (how long the sweep stood still for the exchange) and around the exchange itself on the
+	// comm stream.  Off by default: the records sit between sweeps that otherwise run back to back.
+	bool diagnostics = false, diag_active = false;  // requested / being collected by the crd_step_rk4_timed call in progress
+	std::vector<hipEvent_t> ev_diag;  // 4 per exchange: wait begin / end (compute), exchange begin / end (comm)
+	int diag_waits = 0, diag_exchanges = 0;
+	crd_step_timing timing{};  // filled by crd_step_rk4_timed
 
 	crd::SlabDesc desc{};
 	int stepper = CRD_STEPPER_AUTO;

@@ -59,6 +59,9 @@ int exchange_rccl(crd_ctx *c, Planes pl, int depth, bool with_v)
 	void *fields[2] = {pl.u, pl.v};
 	crd_halo_op ops[4];
 	if (crd_halo_plan(c->slab, c->n_slabs, c->nyl, depth, ops) != CRD_OK) return fail(c, CRD_EINVAL, "bad halo plan");
+	// (diagnostics: the exchange's own duration on the comm stream, from the moment its inputs are ready to its last byte)
+	const bool diag = c->diag_active && 4 * c->diag_exchanges + 3 < (int)c->ev_diag.size();
+	if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_exchanges + 2)], c->comm));
 	NCCL_TRY(c, g_rccl.GroupStart());
 	for (int f = 0; f < (with_v ? 2 : 1); f++)
 		for (const crd_halo_op &op : ops) {
@@ -67,6 +70,7 @@ int exchange_rccl(crd_ctx *c, Planes pl, int depth, bool with_v)
 			else NCCL_TRY(c, g_rccl.Recv(rows, count, dt, op.peer, c->nccl, c->comm));
 		}
 	NCCL_TRY(c, g_rccl.GroupEnd());
+	if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_exchanges++ + 3)], c->comm));
 	return CRD_OK;
 }
 
@@ -93,6 +97,7 @@ int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, 
 {
 	// Several issuing threads (one per device of a LOCAL group): every thread has enqueued the records of its contexts'
 	// edge events before any thread makes a stream wait for a neighbour's.
+	TraceRange range(depth == kGhost ? "crd_halo_exchange(deep)" : "crd_halo_exchange");
 	GroupBarrier *bar = cs[0]->bar;
 	if (bar && !bar->wait()) return fail(cs[0], CRD_ESTATE, "another slab's issuing thread failed");
 	// comm streams wait for the producers of the edge rows

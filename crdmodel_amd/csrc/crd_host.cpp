@@ -1,6 +1,8 @@
 // crd_host.cpp -- host-side pieces of libcrd that need no GPU: geometry, slab extents, stable states, initial
 // conditions, coefficient tables.  Each function cites the reference lines whose behaviour it reproduces.
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdlib>
 #include <cstring>
 
@@ -148,6 +150,21 @@ int crd_halo_plan(int slab, int n_slabs, int64_t nyl, int depth, crd_halo_op ops
 	return CRD_OK;
 }
 
+int crd_cycle_vote(int pos, double vote[2])
+{
+	if (!vote || pos < -1 || pos >= kExchangeEvery) return CRD_EINVAL;
+	vote[0] = (double)pos;  // element-wise MIN over the ranks: min(pos) and -max(pos)
+	vote[1] = -(double)pos;
+	return CRD_OK;
+}
+
+int crd_cycle_agreed(const double reduced[2])
+{
+	if (!reduced) return -1;
+	const double lo = reduced[0], hi = -reduced[1];
+	return (lo == hi && lo >= 0.0 && lo < (double)kExchangeEvery && lo == (double)(int)lo) ? (int)lo : -1;
+}
+
 static double gb_residual_y(double Z, double Y)
 {
 	// v2 - v3 - kf Y of src/GoldbeterModel_torus.cpp:694-695,716
@@ -195,6 +212,22 @@ int crd_steady_state(int model, double beta, double *s0, double *s1)
 	return CRD_OK;
 }
 
+int crd_steady_state_as_printed(int model, double beta, int decimals, double *s0, double *s1)
+{
+	if (decimals < 0 || decimals > 17) return CRD_EINVAL;
+	const int rc = crd_steady_state(model, beta, s0, s1);
+	if (rc != CRD_OK || decimals == 0 || model != CRD_MODEL_GOLDBETER) return rc;
+	// print Z[-1], Y[-1] of one-element numpy arrays (util/GoldbeterModel/SolveGoldbeterODE.py:111): positional notation with
+	// `precision` = 8 digits BEHIND THE DECIMAL POINT for values in [1e-4, 1e8) -- both numbers are O(0.1 .. 10) for any beta the
+	// model is run with -- trailing zeros dropped; fscanf("[%lf] [%lf]") reads the text back (src/GoldbeterModel_torus.cpp:258).
+	for (double *v : {s0, s1}) {
+		char text[64];
+		std::snprintf(text, sizeof text, "%.*f", decimals, *v);
+		*v = std::strtod(text, nullptr);
+	}
+	return CRD_OK;
+}
+
 int crd_initial_conditions(const crd_run_config *cfg, int64_t js, int64_t je, double *y_aos)
 {
 	if (!cfg || !y_aos) return CRD_EINVAL;
@@ -209,7 +242,7 @@ int crd_initial_conditions(const crd_run_config *cfg, int64_t js, int64_t je, do
 	                                                     : (p.vary_beta != 1);
 	double s0 = 0.0, s1 = 0.0;
 	if (needs_steady) {
-		rc = crd_steady_state(p.model, p.beta, &s0, &s1);
+		rc = crd_steady_state_as_printed(p.model, p.beta, cfg->steady_state_decimals, &s0, &s1);
 		if (rc != CRD_OK) return rc;
 	}
 
@@ -309,8 +342,8 @@ double crd_stable_dt(const crd_params *p)
 	} else {
 		lam = 4.0 * D * (1.0 / (g.dx * g.dx) + 1.0 / (g.dy * g.dy));
 	}
-	// Reaction Jacobian bound: FHN |3 - 3u^2| <= ~9 on the limit cycle; Goldbeter's Hill terms are far stiffer.
-	lam += (p->model == CRD_MODEL_FHN) ? 10.0 : 400.0;
+	// Reaction Jacobian bound (documented in crd.h): FHN |3 - 3u^2| <= ~9 on the limit cycle; Goldbeter's Hill terms are far stiffer.
+	lam += (p->model == CRD_MODEL_FHN) ? kFhnReactionRate : kGoldbeterReactionRate;
 	return 2.785 / lam;
 }
 

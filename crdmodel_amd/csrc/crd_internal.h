@@ -16,6 +16,11 @@ constexpr double kFhnEpsilon = 0.36;        // src/FHNmodel_torus.cpp:68
 constexpr double kGbV0 = 1.0, kGbK = 10.0, kGbKf = 1.0, kGbV1 = 7.3, kGbVm2 = 65.0, kGbVm3 = 500.0;
 constexpr double kGbK2 = 1.0, kGbKr = 2.0, kGbKa = 0.9;
 
+// Bounds on the spectral radius of the reaction Jacobian that crd_stable_dt adds to the diffusion operator's (crd.h has the
+// derivation): FHN |d(3u - u^3)/du| = |3 - 3u^2| <= 9 for |u| <= 2 (the limit cycle stays inside), +1 for the v coupling;
+// Goldbeter: spectral radius of the kinetics' Jacobian over 0 <= Z <= 1.5, 0 <= Y <= 3 is 333 (|dv3/dZ| reaches 410 there), rounded up.
+constexpr double kFhnReactionRate = 10.0, kGoldbeterReactionRate = 400.0;
+
 // Rows one fused RK4 step consumes on each side of the rows it produces (one per stage).
 constexpr int kStepHalo = 4;
 // Fused steps between two halo exchanges of a multi-slab run: the exchange moves kStepHalo * kExchangeEvery ghost rows and
@@ -43,6 +48,16 @@ void build_coefficients(const crd_params &p, const crd_grid &g, Coefficients *ou
 void build_beta_rows(const crd_params &p, const crd_grid &g, int64_t j0, int64_t j1, std::vector<double> *out);
 
 bool validate_params(const crd_params &p, std::string *why);
+
+// crd_trace.cpp: roctx ranges (no-ops unless a profiler listens)
+void trace_push(const char *name);
+void trace_pop();
+struct TraceRange {
+	explicit TraceRange(const char *name) { trace_push(name); }
+	~TraceRange() { trace_pop(); }
+	TraceRange(const TraceRange &) = delete;
+	TraceRange &operator=(const TraceRange &) = delete;
+};
 
 const char *model_name(int model);      // "FHNmodel" / "GoldbeterModel"
 const char *surface_name(int surface);  // "torus" / "flat"

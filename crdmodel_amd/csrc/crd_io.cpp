@@ -210,6 +210,7 @@ extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd
 	if (ok && ini.has("Solver.gpus")) I("Solver.gpus", &cfg->n_gpus);
 	if (ok && ini.has("Solver.stepper")) I("Solver.stepper", &cfg->stepper);
 	if (ok && ini.has("Solver.adaptive")) I("Solver.adaptive", &cfg->adaptive);
+	if (ok && ini.has("Solver.steadyStateDigits")) I("Solver.steadyStateDigits", &cfg->steady_state_decimals);
 	if (ok && ini.has("Solver.rtol")) ok = ini.get_double("Solver.rtol", &cfg->rtol, &why);
 	if (ok && ini.has("Solver.atol")) ok = ini.get_double("Solver.atol", &cfg->atol, &why);
 	if (ok && ini.has("Solver.precision")) {
@@ -233,6 +234,10 @@ extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd
 	if (cfg->output_timestep < 1 || !(cfg->t_final > 0.0) || cfg->n_gpus < 1 || !(cfg->dt >= 0.0) || !(cfg->dt_safety > 0.0) || !(cfg->rtol >= 0.0) ||
 	    !(cfg->atol >= 0.0) || !(cfg->rtol + cfg->atol > 0.0)) {
 		set_err(err, err_len, "outputTimestep, tFinal, gpus, dt, dtSafety, rtol or atol out of range");
+		return CRD_EINVAL;
+	}
+	if (cfg->steady_state_decimals < 0 || cfg->steady_state_decimals > 17) {
+		set_err(err, err_len, "Solver.steadyStateDigits must be 0 .. 17");
 		return CRD_EINVAL;
 	}
 	set_err(err, err_len, "");
@@ -341,6 +346,7 @@ extern "C" int crd_writer_open(const crd_run_config *cfg, const char *dir, int s
 extern "C" int crd_writer_write_row(crd_writer *w, const double *y_aos)
 {
 	if (!w || !y_aos || w->f0 < 0) return CRD_EINVAL;
+	crd::TraceRange range("crd_writer_write_row");
 	const int64_t n = w->nxl * w->nyl;
 	const int64_t per_thread = 1 << 16;  // values formatted by one thread per round (<= 1.6 MB of text)
 	const int T = w->threads;

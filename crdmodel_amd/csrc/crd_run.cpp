@@ -4,6 +4,7 @@
 // FHNmodel_torus / FHNmodel_flat / GoldbeterModel_torus / GoldbeterModel_flat it takes exactly one argument, like
 // they do.  Time integration is fixed-step RK4 on the GPU (libcrd) instead of adaptive ARKode.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -31,6 +32,7 @@ struct Options {
 	int adaptive = -1;
 	bool binary = false;       // also write <Model>_<surface>_<var>.NNN.npy (crd_npy_writer)
 	bool binary_only = false;  // ... and no text rows (the text files are created empty; only crdmodel_amd.post reads such a run)
+	bool ref_steady_state = false;  // Goldbeter rest state as the reference reads it from its script's print (8 decimals)
 };
 
 [[noreturn]] void usage(const char *argv0, bool alias)
@@ -40,7 +42,8 @@ struct Options {
 	} else {
 		std::cerr << "Usage: " << argv0
 		          << " --model fhn|goldbeter --surface torus|flat [--gpus G] [--devices D] [--dt DT] [--stepper auto|staged|fused]\n"
-		             "       [--precision 64|32] [--adaptive|--fixed] [--binary|--binary-only] [--outdir DIR] [--quiet] <Config file path>\n";
+		             "       [--precision 64|32] [--adaptive|--fixed] [--binary|--binary-only] [--ref-steady-state] [--outdir DIR] [--quiet]\n"
+		             "       <Config file path>\n";
 	}
 	std::exit(EXIT_FAILURE);
 }
@@ -171,6 +174,7 @@ int main(int argc, char *argv[])
 			else if (s == "--fixed") o.adaptive = 0;
 			else if (s == "--binary") o.binary = true;
 			else if (s == "--binary-only") o.binary = o.binary_only = true;
+			else if (s == "--ref-steady-state") o.ref_steady_state = true;
 			else if (s == "--precision") {
 				const std::string v = next();
 				o.precision = v == "32" ? CRD_PRECISION_F32 : v == "64" ? CRD_PRECISION_F64 : -2;
@@ -209,6 +213,7 @@ int main(int argc, char *argv[])
 	if (o.stepper >= 0) cfg.stepper = o.stepper;
 	if (o.precision >= 0) cfg.params.precision = o.precision;
 	if (o.adaptive >= 0) cfg.adaptive = o.adaptive;
+	if (o.ref_steady_state) cfg.steady_state_decimals = 8;  // numpy's print precision, util/GoldbeterModel/SolveGoldbeterODE.py:111
 	time_t start_t = 0, end_t = 0;
 	double total_t = 0, eta = 0;
 	time(&start_t);
@@ -219,7 +224,8 @@ int main(int argc, char *argv[])
 	const int ndev = o.devices > 0 ? o.devices : G;
 
 	double s0 = 0, s1 = 0;  // banner only, and only printed for a constant beta (src/FHNmodel_torus.cpp:268-271)
-	if (cfg.params.vary_beta == 0 && (rc = crd_steady_state(cfg.params.model, cfg.params.beta, &s0, &s1)) != CRD_OK) return die("crd_steady_state", rc, nullptr);
+	if (cfg.params.vary_beta == 0 && (rc = crd_steady_state_as_printed(cfg.params.model, cfg.params.beta, cfg.steady_state_decimals, &s0, &s1)) != CRD_OK)
+		return die("crd_steady_state", rc, nullptr);
 
 	// Output cadence (src/FHNmodel_torus.cpp:415-429): Nt outputs dTout apart; every interval is an integer number of
 	// equal RK4 steps no longer than the requested / stable step.
@@ -310,8 +316,16 @@ int main(int argc, char *argv[])
 	int status = 0;
 	double adaptive_h = 0.0;
 	long long adaptive_steps = 0, adaptive_rejected = 0;
+	// Rate summary ("keep banner; add steps/s, point-steps/s, GB/s"): wall time spent inside the stepping calls
+	// (they block on the download that follows, so the device work of an interval is inside its bracket) and the steps taken.
+	double stepping_s = 0.0;
+	long long steps_taken = 0;
 	for (int iout = 0; iout < Nt; iout++) {
 		const double t = iout * dTout;
+		char range_name[64];
+		std::snprintf(range_name, sizeof range_name, "crd_run output interval %d/%d", iout + 1, Nt);
+		crd_trace_range_push(range_name);
+		const auto step_t0 = std::chrono::steady_clock::now();
 		auto &buf = (iout & 1) ? host_b : host;  // the other set may still be in the writer's hands
 		if (cfg.adaptive) {
 			// one ARKode(...) call per output interval, src/FHNmodel_torus.cpp:423; the controller's step carries over
@@ -326,9 +340,13 @@ int main(int argc, char *argv[])
 			adaptive_h = as.h_next;
 			adaptive_steps += as.accepted;
 			adaptive_rejected += as.rejected;
+			steps_taken += as.accepted + as.rejected;
 		} else {
 			rc = crd_group_step_rk4(ctx.data(), G, t, dt, steps_per_output);
+			steps_taken += steps_per_output;
 		}
+		for (int k = 0; k < G && rc == CRD_OK; k++) rc = crd_synchronize(ctx[(size_t)k]);
+		stepping_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - step_t0).count();
 		const int set = (iout + 1) & 1;  // the other set of frame buffers may still be in the writer's hands
 		for (int k = 0; k < G && rc == CRD_OK; k++) {
 			if (!o.binary_only) rc = crd_state_download(ctx[(size_t)k], buf[(size_t)k].data(), 1);
@@ -338,22 +356,24 @@ int main(int argc, char *argv[])
 				rc = crd_state_download_rows(ctx[(size_t)k], v, 0, je - js + 1, frame[(size_t)(4 * k + 2 * v + set)]);
 		}
 		// the reference stops at the first failing ARKode call on ANY rank (src/FHNmodel_torus.cpp:424-435): look at every slab
-		double peak = 0;
+		bool blown = false;  // sticky: a NaN / Inf on ANY slab stops the run, whatever the later slabs hold
 		for (int k = 0; k < G && rc == CRD_OK; k++) {
 			double pk = 0;
 			rc = crd_state_max_abs(ctx[(size_t)k], &pk);
-			if (!(pk <= peak)) peak = pk;  // keeps a NaN
+			blown = blown || !std::isfinite(pk);
 		}
-		if (rc != CRD_OK || !std::isfinite(peak)) {
+		if (rc != CRD_OK || blown) {
 			if (rc != CRD_OK) die("crd_group_step_rk4", rc, ctx[0]);
 			std::cerr << "Solver failure, stopping integration\n";  // src/FHNmodel_torus.cpp:433
 			status = 1;
+			crd_trace_range_pop();
 			break;
 		}
 		if (writer.joinable()) writer.join();
 		if (writer_rc != CRD_OK) {
 			die("crd_writer_write_row", writer_rc, nullptr);
 			status = 1;
+			crd_trace_range_pop();
 			break;
 		}
 		writer = std::thread([&wr, &buf, &writer_rc, &npy, &frame, &o, G, set, nvars_out]() {
@@ -375,10 +395,21 @@ int main(int argc, char *argv[])
 			            (int)(eta / 60), ((int)eta % 60));
 			std::fflush(stdout);
 		}
+		crd_trace_range_pop();
 	}
 	if (writer.joinable()) writer.join();
 	if (writer_rc != CRD_OK && status == 0) status = die("crd_writer_write_row", writer_rc, nullptr);
 	if (!o.quiet && cfg.adaptive) std::cout << "\n   steps = " << adaptive_steps << " (+" << adaptive_rejected << " rejected)";
+	if (!o.quiet && steps_taken > 0 && stepping_s > 0.0) {
+		// compulsory-byte model of a step: both fields read once and written once (the one-launch stepper's traffic; the four
+		// stage kernels move 8 x that)
+		const double points = (double)g.nx * (double)g.ny, bytes_per_point_step = 4.0 * (double)value_bytes;
+		char line[256];
+		std::snprintf(line, sizeof line, "\n   rate: %lld steps in %.3f s of stepping = %.1f steps/s, %.4g grid-point-steps/s, %.1f GB/s (%g B per point-step)",
+		              steps_taken, stepping_s, (double)steps_taken / stepping_s, points * (double)steps_taken / stepping_s,
+		              points * (double)steps_taken * bytes_per_point_step / stepping_s / 1e9, bytes_per_point_step);
+		std::cout << line;
+	}
 	if (!o.quiet) std::cout << "\n   ----------------------\n";
 	cleanup();
 	return status;

@@ -126,6 +126,7 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
+				if (timed) c->timed_rows = c->nyl + 2 * ext;  // what crd_dominant_kernel_rows reports for this launch
 				// (nothing to record: the next step runs on the same stream; only the band stream, when there is one, needs
 				// ev_interior, and it is recorded by the step in front of the cycle's last one -- see below)
 				if (c->bands_on_own_stream && q == kExchangeEvery - 2) HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
@@ -136,7 +137,11 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			const bool split = c->nyl >= 4 * kFusedBand;
 			if (c->bands_on_own_stream) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));  // otherwise the bands ran on this very stream
 			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kStepHalo, c->nyl - kStepHalo, 0, 0, c->compute));
+			// (diagnostics: how long does the compute stream stand at this wait?  Zero when the exchange hid under the sweeps)
+			const bool diag = c->diag_active && 4 * c->diag_waits + 1 < (int)c->ev_diag.size();
+			if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits)], c->compute));
 			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits++ + 1)], c->compute));
 			if (c->halo == CRD_HALO_LOCAL) {
 				// LOCAL halos are PULLED by the neighbours from this context's planes: the next step that overwrites those
 				// rows (q = 1) must not start before both neighbours have finished copying them
@@ -176,6 +181,31 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kFusedBand, c->nyl - kFusedBand, 0, 0, c->compute));
 		}
 	}
+	return CRD_OK;
+}
+
+// RCCL runs: one decision for the whole ring on where in the exchange cycle the call starts (see crd_ctx::agree_dev).  begin_
+// enqueues the reduction on the comm stream and returns; finish_ waits for it.  Every rank of the run makes both calls in every
+// fused stepping call, before any other RCCL operation of that call.
+int begin_cycle_agreement(crd_ctx *c, int mine)
+{
+	if (!c->agree_dev) {
+		HIP_TRY(c, hipMalloc((void **)&c->agree_dev, 2 * sizeof(double)));
+		HIP_TRY(c, hipHostMalloc((void **)&c->agree_host, 4 * sizeof(double), hipHostMallocDefault));
+		HIP_TRY(c, hipEventCreateWithFlags(&c->ev_agree, hipEventDisableTiming));
+	}
+	if (crd_cycle_vote(mine, c->agree_host) != CRD_OK) return fail(c, CRD_ESTATE, "exchange-cycle position out of range");
+	HIP_TRY(c, hipMemcpyAsync(c->agree_dev, c->agree_host, 2 * sizeof(double), hipMemcpyHostToDevice, c->comm));
+	NCCL_TRY(c, g_rccl.AllReduce(c->agree_dev, c->agree_dev, 2, ncclDouble, ncclMin, c->nccl, c->comm));
+	HIP_TRY(c, hipMemcpyAsync(c->agree_host + 2, c->agree_dev, 2 * sizeof(double), hipMemcpyDeviceToHost, c->comm));
+	HIP_TRY(c, hipEventRecord(c->ev_agree, c->comm));
+	return CRD_OK;
+}
+
+int finish_cycle_agreement(crd_ctx *c, int *agreed)
+{
+	HIP_TRY(c, hipEventSynchronize(c->ev_agree));
+	*agreed = crd_cycle_agreed(c->agree_host + 2);
 	return CRD_OK;
 }
 
@@ -264,9 +294,25 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		// staged stepper, slabs that disagree -- it starts with an exchange.  (A 20-step call on an 8192 x 1024 slab is 1.2 ms:
 		// an exposed exchange in front of it is several per cent.)
 		int q0 = fused ? lead->cycle_start : -1;  // (decide_cycle_start: one decision for every slab of the run)
+		// Under RCCL that decision has to be the RING's, not this rank's: a rank that alone holds a new state (an upload on that
+		// rank only, a failed call) would prime its halo while its neighbours carry on, and the ring's send / receive sequences
+		// would no longer pair.  So the ranks reduce their positions first.  The reduction (and the host's wait for it) hides
+		// under the call's first step wherever that step involves no exchange of its own (q0 = 0 .. 6: the step is issued
+		// speculatively into the scratch planes and simply issued again, behind an exchange, if the ring turns out to disagree).
+		const bool ring = fused && n == 1 && lead->halo == CRD_HALO_RCCL;
+		bool agreement_pending = false;
 		if (nsteps > 0) {
 			for (int k = 0; k < n; k++) cs[k]->cycle_pos = -1;  // until this call has gone through
+			if (ring) {
+				if (int rc = begin_cycle_agreement(lead, q0)) return rc;
+				agreement_pending = true;
+				if (q0 < 0 || q0 == kExchangeEvery - 1) {  // nothing to issue ahead of the answer
+					if (int rc = finish_cycle_agreement(lead, &q0)) return rc;
+					agreement_pending = false;
+				}
+			}
 			if (q0 < 0) {
+				if (ring && lead->cycle_start >= 0) lead->agreement_restarts++;
 				if (int rc = prime_halo(cs, n, crd_ctx::Y, fused ? kGhost : 1, fused)) return rc;
 				q0 = 0;
 			}
@@ -287,6 +333,21 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 				return rc;
 			}
 			if (timed_step) timed = 1;
+			if (agreement_pending) {  // the first step is on its way: now hear what the ring says
+				int agreed = -1;
+				if (int rc = finish_cycle_agreement(lead, &agreed)) return rc;
+				agreement_pending = false;
+				if (agreed != q0) {
+					// Some rank holds a new state: every rank starts afresh.  The step just issued wrote the scratch planes only (plane Y
+					// is untouched) and is overwritten by the one issued again below, in stream order.
+					lead->agreement_restarts++;
+					if (int rc = prime_halo(cs, n, crd_ctx::Y, kGhost, true)) return rc;
+					q0 = 0;
+					cur = crd_ctx::Y;
+					timed = 0;
+					s = -1;
+				}
+			}
 		}
 		// (several issuing threads: the neighbours read this thread's plane pointers while they enqueue their pulls)
 		if (lead->bar && !lead->bar->wait()) return fail(lead, CRD_ESTATE, "another slab's issuing thread failed");
@@ -334,6 +395,7 @@ int crd_step_rk4(crd_ctx *c, double t0, double dt, int64_t nsteps)
 	if (c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "LOCAL groups step through crd_group_step_rk4");
 	crd_ctx *one[1] = {c};
 	decide_cycle_start(one, 1);
+	TraceRange range("crd_step_rk4");
 	return run_steps(one, 1, t0, dt, nsteps, nullptr);
 }
 
@@ -361,6 +423,7 @@ int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_
 	}
 	const int nthreads = (int)first.size();
 	decide_cycle_start(ctxs, n);
+	TraceRange range("crd_group_step_rk4");
 	if (nthreads <= 1 || nsteps <= 0) return run_steps(ctxs, n, t0, dt, nsteps, nullptr);
 	first.push_back(n);
 	GroupBarrier bar;
@@ -425,6 +488,7 @@ static int rhs_on_planes(crd_ctx *const *cs, int n, double t, int src, int dst)
 static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double tout, const crd_adaptive_options *opt_in, crd_adaptive_stats *stats)
 {
 	crd_ctx *lead = cs[0];
+	TraceRange range("crd_integrate_adaptive");
 	crd_adaptive_options o;
 	crd_adaptive_defaults(&o);
 	if (opt_in) o = *opt_in;
@@ -633,6 +697,9 @@ int crd_plan_launches(crd_ctx *c)
 	if (int rc = set_device(c)) return rc;
 	if (int rc = ensure_timing_events(c)) return rc;  // (a first crd_step_rk4_timed would otherwise create its 128 events inside the region it times)
 	if (resolve_stepper(c) != CRD_STEPPER_FUSED || c->plan.tuned || !c->plan.autotune) return CRD_OK;
+	// After a dense-output call the "scratch" plane SA holds the integrator's own state y_{n+1}, which a resumed
+	// crd_integrate_adaptive continues from: leave it alone (the plan is then measured by the first fixed-step launch instead).
+	if (c->dense.pending) return CRD_OK;
 	// One step of the resident state into the scratch planes, discarded: its first launch is where the plan is measured.  The
 	// state itself (plane Y) is only read; ghost rows may be stale, which only matters to results nobody keeps.
 	FusedCall call = make_fused_call(c, 0.0, 1e-9 * crd_stable_dt(&c->p), crd_ctx::Y, crd_ctx::SA);
@@ -643,19 +710,50 @@ int crd_plan_launches(crd_ctx *c)
 	return CRD_OK;
 }
 
+int crd_set_diagnostics(crd_ctx *c, int on)
+{
+	if (!c) return CRD_EINVAL;
+	c->diagnostics = on != 0;
+	return CRD_OK;
+}
+
+int crd_get_step_timing(const crd_ctx *c, crd_step_timing *out)
+{
+	if (!c || !out) return CRD_EINVAL;
+	*out = c->timing;
+	out->agreement_restarts = c->agreement_restarts;
+	return CRD_OK;
+}
+
 int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double *ms_total, double *kernel_ms, int *launches_per_step)
 {
 	if (!c) return CRD_EINVAL;
 	if (c->halo < 0 || c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "timed stepping needs a single-slab or RCCL context");
 	if (int rc = set_device(c)) return rc;
 	if (int rc = ensure_timing_events(c)) return rc;
+	constexpr int kMaxDiagExchanges = 64;
+	if (c->diagnostics)
+		while ((int)c->ev_diag.size() < 4 * kMaxDiagExchanges) {
+			hipEvent_t e;
+			HIP_TRY(c, hipEventCreate(&e));
+			c->ev_diag.push_back(e);
+		}
 	crd_ctx *one[1] = {c};
 	decide_cycle_start(one, 1);
 	int timed = 0;
+	c->timed_rows = 0;
+	c->diag_waits = c->diag_exchanges = 0;
+	c->diag_active = c->diagnostics && c->halo == CRD_HALO_RCCL;
+	c->timing = crd_step_timing{};
 	HIP_TRY(c, hipEventRecord(c->ev_t0, c->compute));
-	if (int rc = run_steps(one, 1, t0, dt, nsteps, &timed)) return rc;
+	trace_push("crd_step_rk4_timed");
+	const int rc_steps = run_steps(one, 1, t0, dt, nsteps, &timed);
+	trace_pop();
+	c->diag_active = false;
+	if (rc_steps) return rc_steps;
 	HIP_TRY(c, hipEventRecord(c->ev_t1, c->compute));
 	HIP_TRY(c, hipEventSynchronize(c->ev_t1));
+	HIP_TRY(c, hipStreamSynchronize(c->comm));
 	float ms = 0.f;
 	HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
 	if (ms_total) *ms_total = ms;
@@ -667,6 +765,22 @@ int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double 
 	}
 	if (kernel_ms) *kernel_ms = timed ? sum / timed : 0.0;
 	if (launches_per_step) *launches_per_step = (resolve_stepper(c) == CRD_STEPPER_FUSED) ? 1 : 2;
+	crd_step_timing &tm = c->timing;
+	tm.ms_total = ms;
+	tm.kernel_ms = timed ? sum / timed : 0.0;
+	tm.steps = nsteps;
+	tm.halo_waits = c->diag_waits;
+	tm.exchanges = c->diag_exchanges;
+	for (int k = 0; k < c->diag_waits; k++) {
+		float m = 0.f;
+		HIP_TRY(c, hipEventElapsedTime(&m, c->ev_diag[(size_t)(4 * k)], c->ev_diag[(size_t)(4 * k + 1)]));
+		tm.exposed_halo_ms += m;
+	}
+	for (int k = 0; k < c->diag_exchanges; k++) {
+		float m = 0.f;
+		HIP_TRY(c, hipEventElapsedTime(&m, c->ev_diag[(size_t)(4 * k + 2)], c->ev_diag[(size_t)(4 * k + 3)]));
+		tm.exchange_ms += m;
+	}
 	return CRD_OK;
 }
 

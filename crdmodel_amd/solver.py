@@ -47,10 +47,30 @@ def halo_plan(slab, n_slabs, nyl, depth=1):
     return [(bool(o.is_send), o.peer, o.row_begin, o.row_count) for o in ops]
 
 
+def cycle_vote(pos):
+    """What a rank standing at position `pos` of the exchange cycle (-1: ghost rows not trusted) contributes to the agreement."""
+    v = (C.c_double * 2)()
+    check(lib().crd_cycle_vote(pos, v), "crd_cycle_vote")
+    return [v[0], v[1]]
+
+
+def cycle_agreed(reduced):
+    """The ring's common cycle position from the element-wise MIN of the ranks' votes, or -1 (start with an exchange)."""
+    return lib().crd_cycle_agreed((C.c_double * 2)(*reduced))
+
+
 def steady_state(model, beta):
     a, b = C.c_double(), C.c_double()
     m = MODELS[model] if isinstance(model, str) else model
     check(lib().crd_steady_state(m, beta, C.byref(a), C.byref(b)), "crd_steady_state")
+    return a.value, b.value
+
+
+def steady_state_as_printed(model, beta, decimals=8):
+    """The stable state as the reference's Goldbeter programs read it from SolveGoldbeterODE.py's print (numpy: 8 decimals)."""
+    a, b = C.c_double(), C.c_double()
+    m = MODELS[model] if isinstance(model, str) else model
+    check(lib().crd_steady_state_as_printed(m, beta, decimals, C.byref(a), C.byref(b)), "crd_steady_state_as_printed")
     return a.value, b.value
 
 
@@ -70,7 +90,8 @@ def load_ini(path, model, surface):
 
 
 def run_config(params, *, wave_length=0.1, wave_width=0.5, wave_inside=0, output_timestep=1, t_final=1.0,
-               include_all_vars=0, ic_type=0, dt=0.0, dt_safety=0.8, n_gpus=1, stepper=capi.STEPPER_AUTO, adaptive=0, rtol=1e-5, atol=1e-10):
+               include_all_vars=0, ic_type=0, dt=0.0, dt_safety=0.8, n_gpus=1, stepper=capi.STEPPER_AUTO, adaptive=0, rtol=1e-5, atol=1e-10,
+               steady_state_decimals=0):
     cfg = RunConfig()
     cfg.params = params
     cfg.wave_length, cfg.wave_width, cfg.wave_inside = wave_length, wave_width, wave_inside
@@ -78,6 +99,7 @@ def run_config(params, *, wave_length=0.1, wave_width=0.5, wave_inside=0, output
     cfg.include_all_vars, cfg.ic_type = include_all_vars, ic_type
     cfg.dt, cfg.dt_safety, cfg.n_gpus, cfg.stepper = dt, dt_safety, n_gpus, stepper
     cfg.adaptive, cfg.rtol, cfg.atol = adaptive, rtol, atol
+    cfg.steady_state_decimals = steady_state_decimals
     return cfg
 
 
@@ -232,6 +254,16 @@ class Slab:
 
     def synchronize(self):
         self._check(lib().crd_synchronize(self._h), "crd_synchronize")
+
+    def set_diagnostics(self, on):
+        """Per-exchange event pairs in the next step_rk4_timed calls (RCCL contexts): see step_timing()."""
+        self._check(lib().crd_set_diagnostics(self._h, 1 if on else 0), "crd_set_diagnostics")
+
+    def step_timing(self):
+        """What the last step_rk4_timed call measured (crd_step_timing) as a dict."""
+        tm = capi.StepTiming()
+        self._check(lib().crd_get_step_timing(self._h, C.byref(tm)), "crd_get_step_timing")
+        return {f: getattr(tm, f) for f, _ in tm._fields_}
 
     def dominant_kernel_rows(self):
         v = C.c_int64()

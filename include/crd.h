@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CRD_ABI_VERSION 2
+#define CRD_ABI_VERSION 3
 
 typedef enum crd_status {
 	CRD_OK = 0,
@@ -99,7 +99,10 @@ typedef struct crd_run_config {
 	int32_t n_gpus;           /* [Solver] gpus, default 1 */
 	int32_t stepper;          /* [Solver] stepper: CRD_STEPPER_* */
 	int32_t adaptive;         /* [Solver] adaptive = 1: error-controlled steps (crd_integrate_adaptive) instead of a fixed dt */
-	int32_t reserved;
+	int32_t steady_state_decimals; /* [Solver] steadyStateDigits (crd_run --ref-steady-state = 8): 0 = the exact Goldbeter fixed point;
+	                                * n > 0 = that fixed point as the reference receives it, through numpy's print of a one-element
+	                                * array (n digits behind the decimal point; numpy's default is 8) and fscanf
+	                                * (crd_steady_state_as_printed) */
 	double rtol, atol;        /* [Solver] rtol / atol, defaults 1e-5 / 1e-10 (src/FHNmodel_torus.cpp:197-198) */
 } crd_run_config;
 
@@ -130,12 +133,31 @@ int crd_slab_extents(int64_t ny, int slab, int n_slabs, int64_t *js, int64_t *je
  * (src/GoldbeterModel_torus.cpp:254-261). */
 int crd_steady_state(int model, double beta, double *s0, double *s1);
 
+/* The same state the way the reference's Goldbeter programs receive it: `print Z[-1], Y[-1]` of one-element numpy arrays
+ * (util/GoldbeterModel/SolveGoldbeterODE.py:111; numpy prints `decimals` = 8 digits behind the decimal point, e.g.
+ * "[ 0.392] [ 1.64562147]") read back by fscanf("[%lf] [%lf]", ...) (src/GoldbeterModel_torus.cpp:254-261).  decimals = 0, or
+ * the FHN model (computed in C++ by the reference, :242-244): no rounding.  What this cannot reproduce is the error of the
+ * script's own BDF integration towards that point (scipy VODE at its default rtol 1e-6 over 50 time units): the reference's
+ * printed digits agree with these to about that tolerance, not to the last of the eight. */
+int crd_steady_state_as_printed(int model, double beta, int decimals, double *s0, double *s1);
+
 /* Initial conditions of rows [js, je] in the boundary layout (AoS doubles, 2*nx*(je-js+1) values):
  * src/FHNmodel_torus.cpp:285-354, src/FHNmodel_flat.cpp:280-319, src/GoldbeterModel_torus.cpp:313-414,
  * src/GoldbeterModel_flat.cpp:309-379. */
 int crd_initial_conditions(const crd_run_config *cfg, int64_t js, int64_t je, double *y_aos);
 
-/* Largest classical-RK4-stable step of the linearised diffusion operator on this grid (2.785 / lambda_max). */
+/* Largest step the classical RK4 scheme takes stably on this problem: 2.785 / lambda_max (2.785 = the extent of RK4's stability
+ * region on the negative real axis), with
+ *   lambda_max = 4 D (1/(r dx)^2 + 1/((R - r) dy)^2) + D / (r (R - r) dx)      torus: the second differences at theta = pi, where
+ *                                                                              the phi spacing is smallest, plus the advective term
+ *              = 4 D (1/dx^2 + 1/dy^2)                                         flat
+ *              + a bound on the reaction Jacobian: 10 for FitzHugh-Nagumo (|3 - 3 u^2| <= 9 for |u| <= 2, which contains the
+ *                limit cycle, + 1), 400 for Goldbeter (the spectral radius of the kinetics' Jacobian over 0 <= Z <= 1.5,
+ *                0 <= Y <= 3 is 333, the VM3 Hill term's slope in Z reaching 410; rounded up).  On the BASELINE grids the reaction
+ *                term is 0.05 % (FHN) / 2 % (Goldbeter at 4096^2) of lambda_max; it decides on coarse grids (the shipped 100 x 400
+ *                Goldbeter run).
+ * crd_run's default step is dtSafety (0.8) times this, and it is the default cap of crd_integrate_adaptive (h_max = 0).
+ * No reference counterpart: ARKode finds its steps by error control (src/FHNmodel_torus.cpp:365). */
 double crd_stable_dt(const crd_params *p);
 
 /* Output files of one slab, byte-compatible with src/FHNmodel_torus.cpp:376-410,438-455:
@@ -206,6 +228,16 @@ typedef struct crd_halo_op {
 } crd_halo_op;
 int crd_halo_plan(int slab, int n_slabs, int64_t nyl, int depth, crd_halo_op ops[4]);
 
+/* How the ranks of an RCCL ring agree, at the start of a stepping call, where in the deep-halo exchange cycle the ring stands --
+ * as data, like crd_halo_plan, so that the rule can be driven over any transport (the CPU tests use gloo).  Each rank votes
+ * crd_cycle_vote(pos): pos = steps its resident state has taken since its ghost rows were last exchanged (0 .. 7), or -1 for a
+ * state whose ghost rows cannot be trusted (new upload, other stepper, failed call).  The element-wise MIN of the votes over
+ * the ranks (ncclAllReduce in the library) goes to crd_cycle_agreed: the common position when every rank voted the same
+ * non-negative one -- the call carries on there -- else -1: every rank starts with an exchange.  No reference counterpart: the
+ * reference exchanges inside every f() (src/FHNmodel_torus.cpp:521). */
+int crd_cycle_vote(int pos, double vote[2]);
+int crd_cycle_agreed(const double reduced[2]);
+
 /* State transfer in the boundary layout.  host_is_f64 = 1: host buffer holds doubles whatever the device
  * precision (converted on the device); 0: host buffer holds the device precision. */
 int crd_state_upload(crd_ctx *ctx, const void *y_aos_host, int host_is_f64);
@@ -228,7 +260,13 @@ int crd_rhs_device(crd_ctx *ctx, double t, const void *y_aos_dev, void *ydot_aos
 
 /* Fast path that never leaves the GPU: nsteps classical RK4 steps of size dt on the context's resident state,
  * stage k of step n evaluated at t0 + n dt + c_k dt (replaces the ARKode(...) call, src/FHNmodel_torus.cpp:423).
- * Asynchronous; crd_synchronize() waits.  With several slabs every context of the run must make the same call. */
+ * Asynchronous; crd_synchronize() waits.  With several slabs every context of the run must make the same call: stepping is
+ * COLLECTIVE (same t0, dt, nsteps, stepper on every rank, like the reference's ARKode call on every MPI rank).  Calls that only
+ * change one rank's state need not be: crd_state_upload on one rank (a stimulus injected by its owner), or a call that failed
+ * there.  The one-launch stepper carries its deep-halo exchange cycle across calls, so under RCCL every stepping call begins
+ * with a two-value ncclAllReduce in which the ranks agree where in the cycle the ring stands; if any rank holds a new state,
+ * all of them start afresh with an exchange (crd_step_timing.agreement_restarts counts those).  The reduction overlaps the
+ * call's first step except when that step is the one that exchanges. */
 int crd_set_stepper(crd_ctx *ctx, int stepper);
 int crd_step_rk4(crd_ctx *ctx, double t0, double dt, int64_t nsteps);
 int crd_synchronize(crd_ctx *ctx);
@@ -291,6 +329,27 @@ int crd_group_rhs_host(crd_ctx *const *ctxs, int n, double t, const void *const 
 int crd_step_rk4_timed(crd_ctx *ctx, double t0, double dt, int64_t nsteps, double *ms_total, double *kernel_ms,
                        int *launches_per_step);
 
+/* What the last crd_step_rk4_timed call measured, plus -- after crd_set_diagnostics(ctx, 1), on an RCCL context stepping with the
+ * one-launch kernel -- two figures per deep-halo exchange of that call: how long the compute stream stood at its wait for the
+ * halo (event pair around the wait; a few microseconds of queue latency when the exchange hid under the sweeps it is given, the
+ * exposed remainder when it did not), and how long the exchange itself took on the second stream (from "its rows are ready" to
+ * "last byte landed").  Replaces nothing in the reference: its Exchange() is eight blocking MPI_Waits inside f()
+ * (src/FHNmodel_torus.cpp:904-946), all of it exposed.  Diagnostics put event records between sweeps that otherwise run back to
+ * back; leave them off in runs whose rate is being measured. */
+typedef struct crd_step_timing {
+	double ms_total;            /* device time of the batch */
+	double kernel_ms;           /* average duration of the timed launches of the dominant kernel */
+	double exposed_halo_ms;     /* sum over halo_waits */
+	double exchange_ms;         /* sum over exchanges */
+	int64_t steps;
+	int32_t halo_waits;         /* waits measured (at most 64 per call) */
+	int32_t exchanges;          /* exchanges measured */
+	int64_t agreement_restarts; /* stepping calls of this context that started afresh with an exchange because the ring's ranks stood
+	                             * at different positions of the exchange cycle (see crd_step_rk4) */
+} crd_step_timing;
+int crd_set_diagnostics(crd_ctx *ctx, int on);
+int crd_get_step_timing(const crd_ctx *ctx, crd_step_timing *out);
+
 /* Rows of the slab one timed launch of the dominant kernel covers (all of them for a single slab; the interior, i.e. all
  * but the edge rows / bands that are launched separately ahead of the halo exchange, for a multi-slab context). */
 int crd_dominant_kernel_rows(const crd_ctx *ctx, int64_t *rows);
@@ -318,6 +377,14 @@ int crd_get_launch_plan(const crd_ctx *ctx, crd_launch_plan *out);
  * inside the first crd_step_rk4 -- for callers that time their first steps; also creates the events crd_step_rk4_timed uses.  The
  * measurement is skipped when a plan exists or autotuning is off. */
 int crd_plan_launches(crd_ctx *ctx);
+
+/* Named ranges for a profiler's timeline (roctx: `rocprofv3 --marker-trace`), SURVEY section 5.  libcrd puts its own around
+ * step batches (crd_step_rk4 ...), halo exchanges, state transfers and output rows; a host program brackets its phases with
+ * these two (crd_run: one range per output interval, where the reference prints its progress line, src/FHNmodel_torus.cpp:
+ * 457-477).  No-ops unless a profiler is attached (ROCP_TOOL_LIBRARIES in the environment) or CRD_ROCTX=1; the marker library
+ * is bound with dlopen on first use, never linked. */
+void crd_trace_range_push(const char *name);
+void crd_trace_range_pop(void);
 
 /* max |var0| over the slab (blow-up guard; synchronises). */
 int crd_state_max_abs(crd_ctx *ctx, double *out);

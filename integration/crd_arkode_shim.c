@@ -19,25 +19,33 @@ int crd_arkode_attach(const crd_run_config *cfg, int rank, int nprocs, int devic
 	p.precision = sizeof(realtype) == 8 ? CRD_PRECISION_F64 : CRD_PRECISION_F32;
 	crd_ctx *ctx = NULL;
 	int rc = crd_create(&p, rank, nprocs, device, &ctx);
-	if (rc != CRD_OK) return rc;
 	if (nprocs > 1) {
-		unsigned char id[128];
+		/* Every rank takes part in the broadcast whatever happened to it so far: a rank that returned early would leave the
+		 * others blocked in bcast().  Byte 0 carries rank 0's status (its crd_create and crd_comm_unique_id), bytes 1..128 the id. */
+		unsigned char msg[129] = {0};
 		if (!bcast) {
 			crd_destroy(ctx);
 			return CRD_EINVAL;
 		}
-		if (rank == 0 && (rc = crd_comm_unique_id(id)) != CRD_OK) {
+		if (rank == 0) {
+			int rc0 = rc != CRD_OK ? rc : crd_comm_unique_id(msg + 1);
+			msg[0] = (unsigned char)(-rc0); /* crd_status values are 0 .. -7 */
+			if (rc == CRD_OK) rc = rc0;
+		}
+		if (bcast(msg, (int)sizeof msg, comm) != 0 && rc == CRD_OK) rc = CRD_ERCCL;
+		if (rc == CRD_OK && msg[0] != 0) rc = rank == 0 ? -(int)msg[0] : CRD_ERCCL; /* rank 0 could not make an id: nobody joins */
+		if (rc != CRD_OK) {
 			crd_destroy(ctx);
 			return rc;
 		}
-		if (bcast(id, (int)sizeof id, comm) != 0) {
-			crd_destroy(ctx);
-			return CRD_ERCCL;
-		}
-		if ((rc = crd_comm_init_rccl(ctx, id)) != CRD_OK) {
+		/* (collective: if crd_create failed on a rank other than 0, that rank has returned its error above and the ranks that
+		 * get here wait for it -- abort the job on any non-zero return, as the reference does after check_flag, :681-705) */
+		if ((rc = crd_comm_init_rccl(ctx, msg + 1)) != CRD_OK) {
 			crd_destroy(ctx);
 			return rc;
 		}
+	} else if (rc != CRD_OK) {
+		return rc;
 	}
 	*out = ctx;
 	return CRD_OK;

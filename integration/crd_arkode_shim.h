@@ -34,8 +34,12 @@ extern "C" {
 int crd_arkode_f(realtype t, N_Vector y, N_Vector ydot, void *user_data);
 
 /* Creates the rank's context from the run configuration (crd_config_load_ini of the same ini file main() reads, :158-174) and,
- * for nprocs > 1, joins the RCCL ring: `bcast(buf, 128, root 0, comm)` is any 128-byte broadcast -- with MPI,
- * `MPI_Bcast(buf, 128, MPI_BYTE, 0, comm)` wrapped in a two-line function.  The reference's 2-D process grid becomes
+ * for nprocs > 1, joins the RCCL ring: `bcast(buf, bytes, comm)` is any broadcast of `bytes` (129: a status byte + the 128-byte
+ * id) from rank 0 -- with MPI, `MPI_Bcast(buf, bytes, MPI_BYTE, 0, comm)` wrapped in a two-line function.  Every rank always
+ * takes part in that one broadcast, also a rank whose own set-up has failed, and a failure of rank 0 (context, RCCL library,
+ * unique id) is returned by EVERY rank after it, so an error never turns into a hang in bcast.  A crd_create failure on another
+ * rank is returned by that rank only: treat any non-zero return as fatal for the job (MPI_Abort), as the reference treats a
+ * failing check_flag (src/FHNmodel_torus.cpp:681-705).  The reference's 2-D process grid becomes
  * phi-slabs: run it with dims = {1, nprocs} (:724-728).  Returns crd_status; *out is NULL on failure and crd_last_error(NULL)
  * has the text. */
 typedef int (*crd_bcast_fn)(void *buf, int bytes, void *comm);

@@ -6,6 +6,7 @@ one ncclGroup) with gloo isend / irecv.  The compute between exchanges is the CP
 computes on the GPU), so what is verified here is the decomposition, the neighbour / ordering logic -- including the
 two-rank ring where both neighbours are the same peer -- and the per-stage exchange schedule of the staged RK4 stepper.
 """
+import json
 import os
 import socket
 import sys
@@ -142,15 +143,40 @@ def _worker(rank, world, port, result_dir):
         assert np.array_equal(ext[halo:halo + nyl2], refq[js2:je2 + 1])
         assert np.array_equal(ext, refq[np.arange(js2 - halo, je2 + 1 + halo) % ny2])  # and the ghosts are fresh again
 
-        # --- the aggregation bench.py does: max over ranks of the elapsed time --------------------------------
+        # --- bench.py's control plane, the very object it uses (gloo, CPU tensors: each bench process owns ONE RCCL
+        #     communicator, libcrd's): barrier, max of the elapsed times, summed self-check flags, the 128-byte RCCL id from
+        #     rank 0, the set-up roll call and the per-rank diagnostics gathered in rank order -------------------------------
         import torch
 
-        tmax = torch.tensor([float(rank + 1)], dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        assert tmax.item() == float(world)
-        ident = [b"x" * 128 if rank == 0 else None]
-        dist.broadcast_object_list(ident, src=0)  # how the RCCL unique id travels
-        assert ident[0] == b"x" * 128
+        ctl = bench.ControlPlane(world, rank)  # joins the group this worker initialised
+        assert ctl.dist is dist
+        ctl.barrier()
+        assert ctl.max_float(float(rank + 1)) == float(world)
+        assert ctl.sum_ints([rank, 1, int(rank == 1)]) == [world * (world - 1) // 2, world, 1]
+        ident = bytes(range(128)) if rank == 0 else b""
+        assert ctl.broadcast_bytes(ident, 128) == bytes(range(128))
+        assert ctl.gather("" if rank != world - 1 else "rank %d: no device memory" % rank) == [""] * (world - 1) + ["rank %d: no device memory" % (world - 1)]
+        recs = ctl.gather({"rank": rank, "kernel_ms": 0.05 + rank, "exposed_halo_ms": 0.001 * rank})
+        assert [r["rank"] for r in recs] == list(range(world)) and recs[rank]["kernel_ms"] == 0.05 + rank
+        json.dumps(recs)  # what goes into the N > 1 line's `per_rank`
+
+        # --- the ring's agreement on the exchange-cycle position (crd_cycle_vote / crd_cycle_agreed: the rule libcrd applies to
+        #     an ncclAllReduce(MIN) at the start of every fused stepping call), driven over gloo: all ranks at one position ->
+        #     carry on there; any rank with a new state (-1), or ranks at different positions -> everybody exchanges first ----
+        def ring_decision(my_pos):
+            t = torch.tensor(crd.cycle_vote(my_pos), dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return crd.cycle_agreed(t.tolist())
+
+        for pos in range(8):
+            assert ring_decision(pos) == pos
+        assert ring_decision(-1) == -1
+        assert ring_decision(-1 if rank == world - 1 else 5) == -1  # one rank uploaded a new state: every rank hears of it
+        assert ring_decision(-1 if rank == 0 else 0) == -1
+        assert ring_decision(3 if rank == 0 else 4) == -1           # (cannot happen with collective stepping calls; still decided alike)
+        assert ring_decision(7 if rank == 0 else 0) == -1
+        with pytest.raises(crd._capi.CrdError):
+            crd.cycle_vote(8)
         open(os.path.join(result_dir, "ok.%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()

@@ -1,6 +1,7 @@
 """End to end on the GPU: `<program> <ini>` (the reference's command line) -> per-subdomain text files -> the plot
 script's loader logic -> compared with the oracle's trajectory at the output times."""
 import os
+import re
 import shutil
 import subprocess
 
@@ -42,6 +43,13 @@ def test_driver_writes_reference_format(gpu_device, tmp_path, argv):
     if "--quiet" not in argv:
         assert "2D FHN model PDE problem on a torus:" in r.stdout and "nx = 16" in r.stdout and "ny = 40" in r.stdout
         assert "100 %" in r.stdout
+        # the end-of-run rate line SURVEY section 5 asks for: steps/s, grid-point-steps/s, GB/s under the compulsory-byte model
+        m = re.search(r"rate: (\d+) steps in ([0-9.]+) s of stepping = ([0-9.e+]+) steps/s, ([0-9.e+]+) grid-point-steps/s, ([0-9.e+]+) GB/s \(32 B per point-step\)", r.stdout)
+        assert m, r.stdout
+        steps, secs, sps, pps, gbs = int(m.group(1)), float(m.group(2)), float(m.group(3)), float(m.group(4)), float(m.group(5))
+        d_tout = cfg.t_final / cfg.output_timestep
+        assert steps == cfg.output_timestep * int(np.ceil(d_tout / cfg.dt - 1e-12)) and secs > 0
+        assert pps == pytest.approx(16 * 40 * sps, rel=2e-2) and gbs == pytest.approx(pps * 32 / 1e9, rel=2e-2, abs=0.06)
     want = oracle_outputs(cfg)
     u, meta = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "u")
     v, _ = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "v")  # includeAllVars = 1 in this ini
@@ -86,6 +94,51 @@ def test_driver_adaptive_mode(gpu_device, tmp_path):
     assert r.returncode == 0, r.stderr
     u2, meta2 = load_like_the_plot_script(out2, "FHNmodel_torus", "u")
     assert meta2["nprocs"] == 2 and rel_err(u2, want[..., 0]) <= 1e-9
+
+
+def test_driver_stops_when_any_slab_blows_up(gpu_device, tmp_path):
+    """Round-2 advice: the blow-up guard must be sticky over the slabs -- a NaN confined to slab 0 of a two-slab run was
+    overwritten by slab 1's finite maximum and the driver kept writing NaN frames.  A step six times the stability limit
+    overflows within ~90 steps where the field has structure (the initial rectangle, rows 683-1365: all in slab 0 of two) and
+    spreads 4 rows per step, so after the first output interval of 100 steps slab 0 holds NaN and slab 1 is still finite (checked
+    with the library directly); the driver must say "Solver failure", stop and exit non-zero as the reference does
+    (src/FHNmodel_torus.cpp:424-435)."""
+    nx, ny = 64, 4096
+    p = crd.make_params("fhn", "torus", nx, 80.0, 20.0, 0.12, 1.25, ny=ny)
+    dt = 6.0 * crd.stable_dt(p)
+    cfg = crd.run_config(p, wave_length=1.0 / 6.0, wave_width=0.5, wave_inside=0)
+    with crd.LocalGroup(p, 2) as grp:
+        grp.upload(crd.initial_conditions(cfg))
+        grp.step_rk4(0.0, dt, 100)
+        peaks = [s.max_abs() for s in grp.slabs]
+    assert not np.isfinite(peaks[0]) and np.isfinite(peaks[1]), peaks  # the premise: only slab 0 has blown up
+    ini = tmp_path / "blowup.ini"
+    ini.write_text("[Parameters]\ndiffusion = 0.12\nbeta = 1.25\nsurfaceWidth = 20\nsurfaceLength = 80\nwaveLength = %r\nwaveWidth = 0.5\nwaveInside = 0\n"
+                   "outputTimestep = 3\ntBoundary = 0\ntFinal = %r\nthetaMesh = %d\nphiMesh = %d\nbetaMin = 0.7\nbetaMax = 1.7\n\n[System]\nincludeAllVars = 0\n"
+                   "varyBeta = 0\n[Solver]\ndt = %r\n" % (1.0 / 6.0, 300 * dt, nx, ny, dt))
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--gpus", "2", "--devices", "1", "--quiet", str(ini)],
+                       cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "Solver failure, stopping integration" in r.stderr, (r.returncode, r.stderr)
+    rows = np.loadtxt(tmp_path / "FHNmodel_torus_u.001.txt", ndmin=2)
+    assert rows.shape[0] == 1  # the initial row only: nothing was written after the failing interval
+
+
+def test_driver_reference_steady_state_option(gpu_device, tmp_path):
+    """`GoldbeterModel_torus`-style run with --ref-steady-state: banner and initial row carry the rest state rounded the way the
+    reference's print + fscanf pair delivers it (8 decimals), the default run the exact fixed point."""
+    ini = os.path.join(GOLDEN, "ini", "goldbeter_shipped.ini")
+    rows = {}
+    for flag in ("--ref-steady-state", None):
+        d = tmp_path / ("ref" if flag else "exact")
+        d.mkdir()
+        cmd = [os.path.join(BIN, "crd_run"), "--model", "goldbeter", "--surface", "torus"] + ([flag] if flag else []) + [ini]
+        r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert ("Stable state values: Z = 0.392, Y = 1.64562" in r.stdout) and "rate: " in r.stdout
+        rows[flag] = np.loadtxt(d / "GoldbeterModel_torus_Z.000.txt", ndmin=2)[0]
+    zp, _ = crd.steady_state_as_printed("goldbeter", 0.4, 8)
+    z, _ = crd.steady_state("goldbeter", 0.4)
+    assert set(np.unique(rows["--ref-steady-state"])) == {zp, zp + 1.0} and set(np.unique(rows[None])) == {z, z + 1.0}
 
 
 def test_config_c1_flat_256_driver(gpu_device, tmp_path):

@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and the ctypes table binds exactly the declared set, so a header change cannot go unbound
     assert sorted(crd._capi._SIGNATURES) == names
-    assert crd._capi.lib().crd_abi_version() == 2
+    assert crd._capi.lib().crd_abi_version() == 3
 
 
 def test_status_strings():
@@ -91,6 +91,40 @@ def test_steady_states():
     assert crd.steady_state("fhn", 1.25) == (-1.25, 1.25 ** 3 - 3 * 1.25)
     # beta = 0.4 -> (0.392, 1.64562146714406)
     assert crd.steady_state("goldbeter", 0.4) == pytest.approx((0.392, 1.64562146714406), rel=1e-14)
+
+
+def test_goldbeter_steady_state_as_the_reference_reads_it(tmp_path):
+    """`[Solver] steadyStateDigits = 8` / `crd_run --ref-steady-state`: the Goldbeter rest state the way the reference's programs
+    receive it -- numpy's print of one-element arrays, 8 digits behind the decimal point (util/GoldbeterModel/
+    SolveGoldbeterODE.py:111: `print Z[-1], Y[-1]` -> "[ 0.392] [ 1.64562147]"), read back by fscanf("[%lf] [%lf]")
+    (src/GoldbeterModel_torus.cpp:254-261) -- at beta = 0.4 (inside the oscillatory window) and 0.14 (outside)."""
+    for beta in (0.4, 0.14):
+        z, y = crd.steady_state("goldbeter", beta)
+        zp, yp = crd.steady_state_as_printed("goldbeter", beta, 8)
+        # exactly what Python's own "%.8f" -> float round trip gives (numpy then drops trailing zeros: same number)
+        assert (zp, yp) == (float("%.8f" % z), float("%.8f" % y))
+        assert abs(zp - z) <= 5e-9 and 0 < abs(yp - y) <= 5e-9
+        text = "[ %s] [ %s]" % (np.format_float_positional(zp, precision=8, trim="-"), np.format_float_positional(yp, precision=8, trim="-"))
+        back = [float(t.strip("[] ")) for t in text.split("] [")]  # what fscanf("[%lf] [%lf]") extracts
+        assert back == [zp, yp]
+    assert crd.steady_state_as_printed("goldbeter", 0.4, 8) == (0.392, 1.64562147)
+    assert crd.steady_state_as_printed("goldbeter", 0.4, 0) == crd.steady_state("goldbeter", 0.4)
+    assert crd.steady_state_as_printed("fhn", 1.3, 8) == crd.steady_state("fhn", 1.3)  # the FHN state is computed in C++ (:242-244)
+    # through the ini key into the initial conditions: the rectangle sits on (Zs + 1, Ys + 1) of the rounded state
+    base = open(os.path.join(INI, "goldbeter_shipped.ini")).read()
+    ini = tmp_path / "gb.ini"
+    ini.write_text(base + "\n[Solver]\nsteadyStateDigits = 8\n")
+    cfg = crd.load_ini(ini, "goldbeter", "torus")
+    assert cfg.steady_state_decimals == 8 and crd.load_ini(os.path.join(INI, "goldbeter_shipped.ini"), "goldbeter", "torus").steady_state_decimals == 0
+    y0 = crd.initial_conditions(cfg)
+    zp, yp = crd.steady_state_as_printed("goldbeter", cfg.params.beta, 8)
+    assert set(np.unique(y0[..., 0])) == {zp, zp + 1.0} and set(np.unique(y0[..., 1])) == {yp, yp + 1.0}
+    exact = crd.initial_conditions(crd.load_ini(os.path.join(INI, "goldbeter_shipped.ini"), "goldbeter", "torus"))
+    assert 0 < np.abs(exact - y0).max() <= 5e-9
+    bad = tmp_path / "bad.ini"
+    bad.write_text(base + "\n[Solver]\nsteadyStateDigits = 40\n")
+    with pytest.raises(crd._capi.CrdError):
+        crd.load_ini(bad, "goldbeter", "torus")
 
 
 IC_CASES = [
@@ -240,6 +274,61 @@ def test_arkrhsfn_shim_compiles_as_c(tmp_path):
            "-o", str(tmp_path / "shim"), "-L", lib_dir, "-lcrd", "-Wl,-rpath," + lib_dir, "-Wl,-rpath,/opt/rocm/lib", "-lm"]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_arkrhsfn_shim_never_skips_its_broadcast(tmp_path):
+    """crd_arkode_attach with nprocs > 1: every rank takes part in the ONE broadcast whatever happened to it before (round-2
+    advice: a rank that returned early left the others blocked in bcast), and rank 0's failure reaches every rank through the
+    status byte.  Runs without a GPU: there crd_create fails on every rank, which is exactly the situation to get right."""
+    import shutil
+    import subprocess
+
+    if shutil.which("gcc") is None:
+        pytest.skip("gcc not available")
+    src = tmp_path / "bcast.c"
+    src.write_text(r'''
+#include <stdio.h>
+#include <string.h>
+#include "crd_arkode_shim.h"
+static int calls, bytes_seen; static unsigned char root_status;
+static int fake_bcast(void *buf, int bytes, void *comm) {
+	(void)comm; calls++; bytes_seen = bytes;
+	if (root_status) ((unsigned char *)buf)[0] = root_status; /* what a failing rank 0 would have sent */
+	return 0;
+}
+int main(void) {
+	crd_run_config cfg; crd_ctx *ctx = (crd_ctx *)1; int rc;
+	memset(&cfg, 0, sizeof cfg);
+	cfg.params.model = CRD_MODEL_FHN; cfg.params.surface = CRD_SURFACE_TORUS; cfg.params.nx = 32; cfg.params.ny = 64;
+	cfg.params.surface_length = 80.0; cfg.params.surface_width = 20.0; cfg.params.diffusion = 0.12; cfg.params.beta = 1.25;
+	int have_gpu = crd_device_count() > 0;
+	/* rank 0 of 2 */
+	calls = 0; root_status = 0;
+	if (!have_gpu) { /* (with a GPU this rank would go on to wait for a second rank that does not exist) */
+		rc = crd_arkode_attach(&cfg, 0, 2, 0, fake_bcast, NULL, &ctx);
+		if (calls != 1 || bytes_seen != 129 || rc != CRD_EHIP || ctx != NULL) { printf("rank0 %d %d %d\n", calls, bytes_seen, rc); return 1; }
+	}
+	/* rank 1 of 2 told by the status byte that rank 0 failed: one broadcast, an error, no hang in crd_comm_init_rccl */
+	calls = 0; root_status = 3; ctx = (crd_ctx *)1;
+	rc = crd_arkode_attach(&cfg, 1, 2, 0, fake_bcast, NULL, &ctx);
+	if (calls != 1 || rc == CRD_OK || ctx != NULL) { printf("rank1 %d %d\n", calls, rc); return 2; }
+	/* no broadcast function at all */
+	rc = crd_arkode_attach(&cfg, 1, 2, 0, NULL, NULL, &ctx);
+	if (rc != CRD_EINVAL) return 3;
+	printf("ok\n");
+	return 0;
+}
+''')
+    lib_dir = os.path.join(ROOT, "crdmodel_amd")
+    exe = tmp_path / "bcast"
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "integration"),
+           "-I", os.path.join(ROOT, "tests", "native"), '-DCRD_SHIM_NVECTOR_HEADER="mock_nvector.h"',
+           os.path.join(ROOT, "integration", "crd_arkode_shim.c"), str(src), "-o", str(exe), "-L", lib_dir, "-lcrd", "-Wl,-rpath," + lib_dir,
+           "-Wl,-rpath,/opt/rocm/lib", "-lm"]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
 def test_seeded_sweep_of_host_side_rules_against_the_oracle():

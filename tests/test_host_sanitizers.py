@@ -1,5 +1,5 @@
 """The host-only translation units of libcrd (crd_host.cpp: geometry, slabs, halo plan, steady states, ICs; crd_io.cpp: ini
-reader, text writer) under AddressSanitizer + UndefinedBehaviorSanitizer, and under ThreadSanitizer (the writer's thread pool).  GPU code cannot be sanitised on this pool, host
+reader, text writer; crd_trace.cpp: the roctx binding, here with nobody listening) under AddressSanitizer + UndefinedBehaviorSanitizer, and under ThreadSanitizer (the writer's thread pool).  GPU code cannot be sanitised on this pool, host
 code can: it is plain C++, so g++ builds it without the HIP toolchain."""
 import os
 import shutil
@@ -19,7 +19,7 @@ def test_host_entry_points_under_sanitizers(tmp_path, sanitizers):
     cmd = ["g++", "-std=c++17", "-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=" + sanitizers, "-fno-sanitize-recover=all",
            "-I", os.path.join(ROOT, "include"), "-I", CSRC,
            os.path.join(ROOT, "tests", "native", "host_sanitize.cpp"), os.path.join(CSRC, "crd_host.cpp"), os.path.join(CSRC, "crd_io.cpp"),
-           "-o", str(exe), "-lpthread"]
+           os.path.join(CSRC, "crd_trace.cpp"), "-o", str(exe), "-lpthread", "-ldl"]
     build = subprocess.run(cmd, capture_output=True, text=True)
     if build.returncode != 0 and "sanitize" in build.stderr and "cannot find" in build.stderr:
         pytest.skip("sanitizer runtimes not installed")
