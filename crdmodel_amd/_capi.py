@@ -17,6 +17,7 @@ MODEL_FHN, MODEL_GOLDBETER = 0, 1
 SURFACE_TORUS, SURFACE_FLAT = 0, 1
 PRECISION_F64, PRECISION_F32 = 0, 1
 STEPPER_AUTO, STEPPER_STAGED, STEPPER_FUSED = 0, 1, 2
+ADAPT_RK43, ADAPT_ARKODE = 0, 1
 
 MODELS = {"fhn": MODEL_FHN, "goldbeter": MODEL_GOLDBETER}
 SURFACES = {"torus": SURFACE_TORUS, "flat": SURFACE_FLAT}
@@ -58,14 +59,14 @@ class AdaptiveOptions(C.Structure):
 
     _fields_ = [("rtol", C.c_double), ("atol", C.c_double), ("h0", C.c_double), ("safety", C.c_double), ("bias", C.c_double),
                 ("growth", C.c_double), ("shrink", C.c_double), ("max_steps", C.c_int64), ("h_max", C.c_double), ("dense_output", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("method", C.c_int32)]
 
 
 class AdaptiveStats(C.Structure):
     """crd_adaptive_stats"""
 
     _fields_ = [("accepted", C.c_int64), ("rejected", C.c_int64), ("h_last", C.c_double), ("h_next", C.c_double), ("h_min", C.c_double),
-                ("h_max", C.c_double), ("err_last", C.c_double), ("t", C.c_double), ("t_internal", C.c_double)]
+                ("h_max", C.c_double), ("err_last", C.c_double), ("t", C.c_double), ("t_internal", C.c_double), ("h_first", C.c_double)]
 
 
 class RunConfig(C.Structure):

@@ -129,7 +129,7 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	c->plane_bytes = (size_t)(c->nyl + 2 * kGhost) * (size_t)c->nx * c->real_size;
 	c->halo = n_slabs == 1 ? CRD_HALO_SELF : -1;  // multi-slab contexts must be wired before use
 	if (const char *e = std::getenv("CRD_BAND_STREAM")) c->bands_on_own_stream = std::atoi(e) != 0;
-	if (const char *e = std::getenv("CRD_AUTOTUNE")) c->plan.autotune = c->plan_embed.autotune = std::atoi(e) != 0;
+	if (const char *e = std::getenv("CRD_AUTOTUNE")) c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = std::atoi(e) != 0;
 
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bail(fail(c, CRD_EHIP, "no HIP device available (libcrd has no CPU fallback)"));
@@ -375,6 +375,7 @@ int crd_state_upload(crd_ctx *c, const void *y, int host_is_f64)
 	const size_t bytes = 2 * (size_t)c->nx * (size_t)c->nyl * (host_is_f64 ? 8 : 4);
 	if (int rc = ensure_staging(c, 2 * (size_t)c->nx * (size_t)c->nyl * 8)) return rc;
 	c->dense.pending = false;  // a new state: nothing to resume
+	c->ark.live = false;       // ... and a controller history that belongs to the old one
 	c->cycle_pos = -1;         // ... and ghost rows that belong to the old one
 	HIP_TRY(c, hipMemcpyAsync(c->stage_in, y, bytes, hipMemcpyHostToDevice, c->compute));
 	HIP_TRY(c, launch_aos_to_planes(c->p.precision, host_is_f64, c->stage_in, c->planes(crd_ctx::Y), c->nx, c->nyl, c->compute));
@@ -586,8 +587,8 @@ int crd_synchronize(crd_ctx *c)
 int crd_set_autotune(crd_ctx *c, int on)
 {
 	if (!c) return CRD_EINVAL;
-	c->plan.autotune = c->plan_embed.autotune = on != 0;
-	if (!on) c->plan.tuned = c->plan_embed.tuned = 0;  // back to the plain plan
+	c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = on != 0;
+	if (!on) c->plan.tuned = c->plan_embed.tuned = c->plan_arkode.tuned = 0;  // back to the plain plan
 	return CRD_OK;
 }
 

@@ -136,6 +136,16 @@ struct crd_ctx {
 		double t_out = 0.0, t_n = 0.0, t_np1 = 0.0;
 	} dense;
 
+	// Memory of the ARKode-style controller (CRD_ADAPT_ARKODE) between calls, as ARKodeMem keeps it between ARKode() calls: valid
+	// while the resident state is the one the integrator left (`live`), dropped by whatever replaces that state.
+	struct {
+		bool live = false;
+		int64_t nst = 0;         // steps taken since the state was new
+		double tn = 0.0;         // time the integrator has reached
+		double h = 0.0, hprime = 0.0, eta = 1.0, etamax = 0.0;
+		double ehist[3] = {1.0, 1.0, 1.0};
+	} ark;
+
 	// Multi-slab fused stepping: position in the deep-halo exchange cycle the resident state is at (steps taken since the ghost
 	// rows were last exchanged, 0 = just exchanged), or -1 when the ghost rows cannot be trusted (new state, another stepper,
 	// an error): crd_step_rk4 then starts with an exchange, otherwise it carries on where the previous call stopped.
@@ -161,7 +171,7 @@ struct crd_ctx {
 
 	crd::SlabDesc desc{};
 	int stepper = CRD_STEPPER_AUTO;
-	crd::FusedPlan plan{}, plan_embed{};  // launch plans of the one-launch step (plain / with the embedded error estimate)
+	crd::FusedPlan plan{}, plan_embed{}, plan_arkode{};  // launch plans of the one-launch step (plain / RK4(3) estimate / Zonneveld 5(3)4)
 
 	int halo = CRD_HALO_SELF;
 	std::vector<crd_ctx *> group;  // LOCAL: all contexts of the run, by slab index

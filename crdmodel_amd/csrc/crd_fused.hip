@@ -120,7 +120,7 @@ struct FusedArgs {
 	const Real *in_u, *in_v;  // y0, pointers to local row 0 (ghost rows at negative offsets)
 	Real *out_u, *out_v;      // new state, local row 0
 	Real h2, h3, h6, h1;      // dt/2, dt/3, dt/6, dt
-	int absorb[4];            // t_stage < tBoundary for the four stages
+	int absorb[5];            // t_stage < tBoundary for the four stages (+ the embedded pair's fifth)
 	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
 	int row_begin, row_end;   // rows of the slab this launch produces ...
 	int row_begin2, row_end2; // ... plus an optional second range (the two edge bands of a slab go in one launch)
@@ -136,24 +136,34 @@ struct FusedArgs {
 
 // ABSORB = false compiles the absorbing-row selects out (no stage of the step has t < tBoundary: every launch after the
 // switch-off time, and every launch of a run with tBoundary = 0).
-// EMBED = true adds a fifth pipeline stage, k5 = f(t + dt, y_new), the third-order embedded solution
-//   yhat = y + dt (k1/6 + k2/3 + k3/3 + k5/6)            (order conditions checked in DESIGN.md)
-// and with it the local error estimate y_new - yhat = dt (k4 - k5)/6, whose weighted square sum
+// EMBED adds a fifth pipeline stage and with it a local error estimate whose weighted square sum
 //   sum_i (err_i / (rtol |y_n,i| + atol))^2
 // over this work item's outputs is written to err_partials[item] (ARKode's WRMS norm, src/FHNmodel_torus.cpp:365, is
 // sqrt(sum / N)).  The propagated solution is classical RK4 either way.  The pipeline is then five rows / columns deep
-// (apron 5, 54 valid lanes) and uses 6 register slots per array, the loop being unrolled 6 times (165 VGPRs in fp64, three
-// wavefronts per SIMD; with 8 slots it was 203 and two).
-template <typename Real, int MODEL, bool ABSORB, bool EMBED>
+// (apron 5, 54 valid lanes) and uses 6 register slots per array, the loop being unrolled 6 times.
+//   EMBED = 1  the RK4(3) pair of rounds 1-2: k5 = f(t + dt, y_new), yhat = y + dt (k1/6 + k2/3 + k3/3 + k5/6), err = dt (k4 - k5)/6.
+//   EMBED = 2  ARKode's default fourth-order explicit table, Zonneveld 5(3)4 (what the reference integrates with,
+//              src/FHNmodel_torus.cpp:356-372; table and order conditions in oracle/arkode_erk.py): the fifth stage is
+//              k5 = f(t + 3/4 dt, y + dt (5/32 k1 + 7/32 k2 + 13/32 k3 - 1/32 k4)) and
+//              err = y_new - yhat = dt (2/3 k1 - 2 k2 - 2 k3 - 2 k4 + 16/3 k5).
+//              No accumulators in this variant: when stage 4 of a row runs, the row's stage values y1 = y + dt/2 k1,
+//              y2 = y + dt/2 k2, y3 = y + dt k3 are still in their register slots (six rows deep), so with
+//              d_i = y_i - y the three combinations the row needs come out of d1, d2, d3 and dt k4 there and then,
+//                y_new = y + (d1 + 2 d2 + d3)/3 + dt k4/6,   z5 = y + 5/16 d1 + 7/16 d2 + 13/32 d3 - dt k4/32,
+//                e4 = 4/3 d1 - 4 d2 - 2 d3 - 2 dt k4        (err = e4 + 16/3 dt k5 one iteration later);
+//              the subtractions are exact (y_i is within a factor 2 of y wherever it matters), so what this costs against running
+//              sums is a rounding of y_i itself, 1e-16 |y| in quantities that are compared with rtol |y| + atol.
+template <typename Real, int MODEL, bool ABSORB, int EMBED>
 __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
-	constexpr int APRON = EMBED ? kApron + 1 : kApron;
+	constexpr bool ZONN = EMBED == 2;
+	constexpr int APRON = EMBED != 0 ? kApron + 1 : kApron;
 	constexpr int VALID = kLanes - 2 * APRON;
 	// Register slots per pipeline array = unroll factor: the rows alive at once (4, or 6 with the fifth stage) -- even, because
 	// the two-deep arrays below are addressed with the slot's parity.
-	constexpr int M = EMBED ? CRD_EMBED_SLOTS : 4;
-	static_assert(M % 2 == 0 && M >= (EMBED ? 6 : 4), "slot count");
-	constexpr int kPrefetch = EMBED ? ((MODEL == CRD_MODEL_GOLDBETER && sizeof(Real) == 8) ? 2 : CRD_PREFETCH_EMBED) : (MODEL == CRD_MODEL_GOLDBETER) ? CRD_PREFETCH_GB : CRD_PREFETCH_FHN;
+	constexpr int M = EMBED != 0 ? CRD_EMBED_SLOTS : 4;
+	static_assert(M % 2 == 0 && M >= (EMBED != 0 ? 6 : 4) && (EMBED != 2 || M % 3 == 0), "slot count");
+	constexpr int kPrefetch = EMBED != 0 ? ((MODEL == CRD_MODEL_GOLDBETER && sizeof(Real) == 8) ? 2 : CRD_PREFETCH_EMBED) : (MODEL == CRD_MODEL_GOLDBETER) ? CRD_PREFETCH_GB : CRD_PREFETCH_FHN;
 	static_assert(M % kPrefetch == 0, "prefetch slots are addressed with the unrolled iteration index");
 	const int lane = threadIdx.x & (kLanes - 1);
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
@@ -223,16 +233,22 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 
 	// Pipeline registers.  Row jbase+m of an array lives in slot m mod M (m & 1 for the two-deep v arrays), so with the
 	// loop unrolled M times every access has a compile-time slot and no value is ever moved between registers.
-	Real u0[M], v0[M], U1[M], U2[M], U3[M], V1[2], V2[2], V3[2], aU[M], aV[M];
+	// (Zonneveld variant: the local field's stage values stay until the row's stage 4 has used them -- y1 four rows, y2 three)
+	constexpr int NV1 = ZONN ? M : 2, NV2 = ZONN ? 3 : 2;
+	Real u0[M], v0[M], U1[M], U2[M], U3[M], V1[NV1], V2[NV2], V3[2], aU[M], aV[M];
 	// (Keeping aU / aV in LDS instead -- 90 VGPRs, five wavefronts per SIMD -- measured 3-5 % SLOWER on every grid: the twelve LDS
 	// accesses per iteration cost more than the fifth wavefront brings.)
 #define ACC_U(S) aU[S]
 #define ACC_V(S) aV[S]
-	Real U4[M], V4[2], K4U[2], K4V[2];  // EMBED: y_new window and k4 of the last two rows
+	Real U4[M], V4[2], K4U[2], K4V[2];  // EMBED 1: y_new window and k4 of the last two rows; EMBED 2: z5 window (three rows deep) and e4
 	Real err2 = (Real)0;
 #pragma unroll
 	for (int k = 0; k < M; k++) u0[k] = v0[k] = U1[k] = U2[k] = U3[k] = aU[k] = aV[k] = U4[k] = (Real)0;
-	V1[0] = V1[1] = V2[0] = V2[1] = V3[0] = V3[1] = V4[0] = V4[1] = K4U[0] = K4U[1] = K4V[0] = K4V[1] = (Real)0;
+#pragma unroll
+	for (int k = 0; k < NV1; k++) V1[k] = (Real)0;
+#pragma unroll
+	for (int k = 0; k < NV2; k++) V2[k] = (Real)0;
+	V3[0] = V3[1] = V4[0] = V4[1] = K4U[0] = K4U[1] = K4V[0] = K4V[1] = (Real)0;
 
 	// Rows are fetched kPrefetch iterations before they enter the pipeline: with ~16 wavefronts per CU one row in flight
 	// per wavefront is far too little to cover HBM latency (Little's law), four rows (8 loads, 4 KiB per wavefront) is enough.
@@ -264,6 +280,10 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		// slots of rows p, p-1, ... p-6 (with M = 4, row p-4 shares its slot with row p)
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M;
 		constexpr int S5 = (K + 2 * M - 5) % M, S6 = (K + 2 * M - 6) % M;
+		// slots of the local field's stage values (two deep; in the Zonneveld variant as deep as they have to live) and of the z5 window
+		constexpr int A1 = ZONN ? S1 : (S1 & 1), A2 = ZONN ? S2 : (S2 & 1), A4 = ZONN ? S4 : (S4 & 1);              // y1 rows p-1, p-2, p-4
+		constexpr int B2 = ZONN ? S2 % 3 : (S2 & 1), B3 = ZONN ? S3 % 3 : (S3 & 1), B4 = ZONN ? S4 % 3 : (S4 & 1);  // y2 rows p-2, p-3, p-4
+		constexpr int Z4 = ZONN ? S4 % 3 : S4, Z5 = ZONN ? S5 % 3 : S5, Z6 = ZONN ? S6 % 3 : S6;                    // z5 / y_new rows p-4, p-5, p-6
 		constexpr int P = K % kPrefetch;
 		const int p = jbase + m;
 		const Real b4 = bq[S4];  // b of row p-4 (stage 4), read before row p takes over the slot when M = 4
@@ -284,43 +304,64 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 			rhs_point<Real, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
 			                       ABSORB && a.absorb[0] && boundary_row(c), du, dv);
 			U1[S1] = fmadd(a.h2, du, u0[S1]);
-			V1[S1 & 1] = fmadd(a.h2, dv, v0[S1]);
-			ACC_U(S1) = fmadd(a.h6, du, u0[S1]);
-			ACC_V(S1) = fmadd(a.h6, dv, v0[S1]);
+			V1[A1] = fmadd(a.h2, dv, v0[S1]);
+			if (!ZONN) {
+				ACC_U(S1) = fmadd(a.h6, du, u0[S1]);
+				ACC_V(S1) = fmadd(a.h6, dv, v0[S1]);
+			}
 		}
 		// ---- stage 2, centre row p-2: y1 rows p-3, p-2, p-1 ---------------------------------------------------
 		if (!GUARDED || m >= 4) {
 			const int c = p - 2;
-			rhs_point<Real, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[S2 & 1], cA, cX, cP, bq[S2], ka4,
+			rhs_point<Real, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[A2], cA, cX, cP, bq[S2], ka4,
 			                       ABSORB && a.absorb[1] && boundary_row(c), du, dv);
 			U2[S2] = fmadd(a.h2, du, u0[S2]);
-			V2[S2 & 1] = fmadd(a.h2, dv, v0[S2]);
-			ACC_U(S2) = fmadd(a.h3, du, ACC_U(S2));
-			ACC_V(S2) = fmadd(a.h3, dv, ACC_V(S2));
+			V2[B2] = fmadd(a.h2, dv, v0[S2]);
+			if (!ZONN) {
+				ACC_U(S2) = fmadd(a.h3, du, ACC_U(S2));
+				ACC_V(S2) = fmadd(a.h3, dv, ACC_V(S2));
+			}
 		}
 		// ---- stage 3, centre row p-3: y2 rows p-4, p-3, p-2 ---------------------------------------------------
 		if (!GUARDED || m >= 6) {
 			const int c = p - 3;
-			rhs_point<Real, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[S3 & 1], cA, cX, cP, bq[S3], ka4,
+			rhs_point<Real, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[B3], cA, cX, cP, bq[S3], ka4,
 			                       ABSORB && a.absorb[2] && boundary_row(c), du, dv);
 			U3[S3] = fmadd(a.h1, du, u0[S3]);
 			V3[S3 & 1] = fmadd(a.h1, dv, v0[S3]);
-			ACC_U(S3) = fmadd(a.h3, du, ACC_U(S3));
-			ACC_V(S3) = fmadd(a.h3, dv, ACC_V(S3));
+			if (!ZONN) {
+				ACC_U(S3) = fmadd(a.h3, du, ACC_U(S3));
+				ACC_V(S3) = fmadd(a.h3, dv, ACC_V(S3));
+			}
 		}
 		// ---- stage 4, centre row p-4: y3 rows p-5, p-4, p-3 -> the new state ----------------------------------
 		if (!GUARDED || m >= 8) {
 			const int c = p - 4;
 			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
 			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);
-			const Real nu = fmadd(a.h6, du, ACC_U(S4)), nv = fmadd(a.h6, dv, ACC_V(S4));
+			Real nu, nv;
+			if (ZONN) {
+				// everything the row still needs, from its stage values (see the kernel's header comment)
+				const Real yu = u0[S4], yv = v0[S4];
+				const Real d1u = U1[S4] - yu, d2u = U2[S4] - yu, d3u = U3[S4] - yu, d1v = V1[A4] - yv, d2v = V2[B4] - yv, d3v = V3[S4 & 1] - yv;
+				nu = fmadd((Real)(1.0 / 3.0), fmadd((Real)2, d2u, d1u + d3u), fmadd(a.h6, du, yu));
+				nv = fmadd((Real)(1.0 / 3.0), fmadd((Real)2, d2v, d1v + d3v), fmadd(a.h6, dv, yv));
+				const Real h32 = (Real)(-1.0 / 32.0) * a.h1, h2m = (Real)-2 * a.h1;
+				U4[Z4] = fmadd((Real)(5.0 / 16.0), d1u, fmadd((Real)(7.0 / 16.0), d2u, fmadd((Real)(13.0 / 32.0), d3u, fmadd(h32, du, yu))));
+				V4[S4 & 1] = fmadd((Real)(5.0 / 16.0), d1v, fmadd((Real)(7.0 / 16.0), d2v, fmadd((Real)(13.0 / 32.0), d3v, fmadd(h32, dv, yv))));
+				K4U[S4 & 1] = fmadd((Real)(4.0 / 3.0), d1u, fmadd((Real)-4, d2u, fmadd((Real)-2, d3u, h2m * du)));
+				K4V[S4 & 1] = fmadd((Real)(4.0 / 3.0), d1v, fmadd((Real)-4, d2v, fmadd((Real)-2, d3v, h2m * dv)));
+			} else {
+				nu = fmadd(a.h6, du, ACC_U(S4));
+				nv = fmadd(a.h6, dv, ACC_V(S4));
+			}
 			// Without the fifth stage rows j0 <= c < j1 are exactly iterations 8 .. niter-1; with it (one more apron row each side)
 			// the first and the last iteration of the range fall outside.
-			if ((!EMBED || (c >= j0 && c < j1)) && lane_stores) {
+			if ((EMBED == 0 || (c >= j0 && c < j1)) && lane_stores) {
 				*at_lane(out_row_u, ob) = nu;
 				*at_lane(out_row_v, ob) = nv;
 			}
-			if (EMBED) {
+			if (EMBED == 1) {
 				U4[S4] = nu;
 				V4[S4 & 1] = nv;
 				K4U[S4 & 1] = du;
@@ -328,14 +369,21 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 			}
 		}
 		// ---- stage 5 (EMBED), centre row p-5: y_new rows p-6, p-5, p-4 -> k5 and the error of row p-5 ----------
-		if (EMBED && (!GUARDED || m >= 10)) {
+		if (EMBED != 0 && (!GUARDED || m >= 10)) {
 			const int c = p - 5;
-			rhs_point<Real, MODEL>(U4[S5], from_lane_below(U4[S5]), from_lane_above(U4[S5]), U4[S6], U4[S4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
-			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);  // k5 is evaluated at t + dt, like k4
+			rhs_point<Real, MODEL>(U4[Z5], from_lane_below(U4[Z5]), from_lane_above(U4[Z5]), U4[Z6], U4[Z4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
+			                       ABSORB && a.absorb[4] && boundary_row(c), du, dv);  // k5 at t + dt like k4 (EMBED 1) or at t + 3/4 dt (Zonneveld)
 			if (lane_stores) {  // rows j0 .. j1-1 exactly: stage 5 starts at iteration 10 (row j0) and the loop ends at row j1-1
 				const Real au = u0[S5] < (Real)0 ? -u0[S5] : u0[S5], av = v0[S5] < (Real)0 ? -v0[S5] : v0[S5];
-				const Real eu = a.h6 * (K4U[S5 & 1] - du) / fmadd(a.rtol, au, a.atol);
-				const Real ev = a.h6 * (K4V[S5 & 1] - dv) / fmadd(a.rtol, av, a.atol);
+				Real eu, ev;
+				if (ZONN) {
+					const Real h163 = (Real)(16.0 / 3.0) * a.h1;
+					eu = fmadd(h163, du, K4U[S5 & 1]) / fmadd(a.rtol, au, a.atol);
+					ev = fmadd(h163, dv, K4V[S5 & 1]) / fmadd(a.rtol, av, a.atol);
+				} else {
+					eu = a.h6 * (K4U[S5 & 1] - du) / fmadd(a.rtol, au, a.atol);
+					ev = a.h6 * (K4V[S5 & 1] - dv) / fmadd(a.rtol, av, a.atol);
+				}
 				err2 = fmadd(eu, eu, fmadd(ev, ev, err2));
 			}
 		}
@@ -359,7 +407,7 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::false_type{});
 	    },
 	    std::make_integer_sequence<int, M - 1>{});
-	if constexpr (EMBED) {
+	if constexpr (EMBED != 0) {
 		// wavefront sum in a fixed order (butterfly over lane distances 32 .. 1), one partial per work item: the host-side
 		// reduction adds them in item order, so the norm is reproducible run to run
 		double sum = (double)err2;
@@ -410,7 +458,7 @@ int resident_wavefronts()
 		int dev = 0, cus = 256, blocks_per_cu = 4;
 		hipDeviceProp_t prop;
 		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, false>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
 		    blocks_per_cu < 1)
 			blocks_per_cu = 4;
 		(void)hipGetLastError();
@@ -474,7 +522,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.h3 = (Real)(c.dt / 3.0);
 	a.h6 = (Real)(c.dt / 6.0);
 	a.h1 = (Real)c.dt;
-	for (int k = 0; k < 4; k++) a.absorb[k] = c.absorb[k];
+	for (int k = 0; k < 5; k++) a.absorb[k] = c.absorb[k];
 	a.js = js;
 	a.ny = ny;
 	a.row_begin = row_begin;
@@ -498,7 +546,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.atol = (Real)c.atol;
 	// the reaction block of a diffusion-only run is skipped, absorbing rows included (src/GoldbeterModel_torus.cpp:668)
 	constexpr bool kCanAbsorb = MODEL != kModelDiffusionOnly;
-	const bool absorb = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3]);
+	const bool absorb = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3] || (c.embed && c.absorb[4]));
 	const dim3 block(kLanes * sw);
 
 	auto configure = [&](int one_round, int remap) {
@@ -524,13 +572,19 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	auto fire = [&]() -> hipError_t {
 		if (c.embed) {
 			if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
-			if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, true><<<a.nblocks, block, 0, st>>>(s, a);
-			else crd_rk4_fused_step_kernel<Real, MODEL, false, true><<<a.nblocks, block, 0, st>>>(s, a);
+			if (c.embed == 2) {
+				if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 2><<<a.nblocks, block, 0, st>>>(s, a);
+				else crd_rk4_fused_step_kernel<Real, MODEL, false, 2><<<a.nblocks, block, 0, st>>>(s, a);
+			} else if (absorb) {
+				crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 1><<<a.nblocks, block, 0, st>>>(s, a);
+			} else {
+				crd_rk4_fused_step_kernel<Real, MODEL, false, 1><<<a.nblocks, block, 0, st>>>(s, a);
+			}
 			crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
 		} else if (absorb) {
-			crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, false><<<a.nblocks, block, 0, st>>>(s, a);
+			crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 0><<<a.nblocks, block, 0, st>>>(s, a);
 		} else {
-			crd_rk4_fused_step_kernel<Real, MODEL, false, false><<<a.nblocks, block, 0, st>>>(s, a);
+			crd_rk4_fused_step_kernel<Real, MODEL, false, 0><<<a.nblocks, block, 0, st>>>(s, a);
 		}
 		return launch_status();
 	};

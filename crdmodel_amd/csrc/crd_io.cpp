@@ -236,6 +236,10 @@ extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd
 		set_err(err, err_len, "outputTimestep, tFinal, gpus, dt, dtSafety, rtol or atol out of range");
 		return CRD_EINVAL;
 	}
+	if (cfg->adaptive < 0 || cfg->adaptive > 2) {
+		set_err(err, err_len, "Solver.adaptive must be 0 (fixed step), 1 (ARKode-style) or 2 (RK4(3))");
+		return CRD_EINVAL;
+	}
 	if (cfg->steady_state_decimals < 0 || cfg->steady_state_decimals > 17) {
 		set_err(err, err_len, "Solver.steadyStateDigits must be 0 .. 17");
 		return CRD_EINVAL;

@@ -67,11 +67,11 @@ struct FusedPlan {
 
 struct FusedCall {
 	double dt;
-	int absorb[4];
+	int absorb[5];  // four stages + the embedded pair's fifth (embed = 1: t + dt; embed = 2: t + 3/4 dt)
 	Planes y0;
 	Planes yout;
 	// embedded error estimate (adaptive stepping): weighted square sum of the local error over the launch's rows
-	int embed = 0;
+	int embed = 0;  // 0: none; 1: RK4(3), k5 = f(t + dt, y_new); 2: Zonneveld 5(3)4 (ARKode's default fourth-order table)
 	double rtol = 0.0, atol = 0.0;
 	double *err_partials = nullptr;  // device scratch, err_capacity doubles (>= fused_max_items)
 	int err_capacity = 0;
@@ -92,6 +92,15 @@ hipError_t launch_aos_row_extract(int precision, const void *aos, void *row, int
 
 // out = cubic Hermite interpolant at t_n + theta h of the step (yn, fn) -> (yp, fp); owned rows of both fields.
 hipError_t launch_hermite(int precision, Planes yn, Planes yp, Planes fn, Planes fp, Planes out, int nx, int nyl, double theta, double h, hipStream_t s);
+
+// The vector operations of ARKode's initial-step estimate on the owned rows of both fields (arkHin; oracle/arkode_erk.py):
+//   launch_hin_bound   *out = max_i |f_i| / (0.1 |y_i| + rtol |y_i| + atol)
+//   launch_axpy_planes out = y + h f
+//   launch_ydd_sumsq   *out = sum_i (((f2_i - f0_i) / h) / (rtol |y_i| + atol))^2, added in a fixed order (partials_dev: >= 256 doubles)
+hipError_t launch_hin_bound(int precision, Planes y, Planes f, int nx, int nyl, double rtol, double atol, double *out_dev, hipStream_t s);
+hipError_t launch_axpy_planes(int precision, Planes y, Planes f, double h, Planes out, int nx, int nyl, hipStream_t s);
+hipError_t launch_ydd_sumsq(int precision, Planes y, Planes f0, Planes f2, double h, double rtol, double atol, int nx, int nyl, double *partials_dev, double *out_dev,
+                            hipStream_t s);
 
 // max |u| over the owned rows, written to *out (device double).
 hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s);

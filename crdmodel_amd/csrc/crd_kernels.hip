@@ -388,6 +388,114 @@ hipError_t launch_hermite(int precision, Planes yn, Planes yp, Planes fn, Planes
 	return launch_status();
 }
 
+// ---- the three vector operations of ARKode's initial-step estimate (arkHin / arkUpperBoundH0 / arkYddNorm, restated in
+// oracle/arkode_erk.py; the reference gets them from ARKodeInit + the first ARKode call, src/FHNmodel_torus.cpp:362,423) ----
+
+// max_i |f_i| / (0.1 |y_i| + rtol |y_i| + atol) over one field, folded into *out with an atomic max on the bit pattern
+template <typename Real>
+__global__ void __launch_bounds__(256) crd_hin_bound_kernel(const Real *__restrict__ y, const Real *__restrict__ f, size_t n, double rtol, double atol, double *out)
+{
+	__shared__ double part[4];
+	double m = 0.0;
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+		const double ay = fabs((double)y[q]);
+		const double r = fabs((double)f[q]) / (0.1 * ay + (rtol * ay + atol));
+		m = (r > m || r != r) ? r : m;
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		const double o = __shfl_down(m, off, 64);
+		m = (o > m || o != o) ? o : m;
+	}
+	if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+	__syncthreads();
+	if (threadIdx.x == 0) {
+		for (int w = 1; w < 4; w++) m = (part[w] > m || part[w] != part[w]) ? part[w] : m;
+		atomicMax(reinterpret_cast<unsigned long long *>(out), (unsigned long long)__double_as_longlong(m));
+	}
+}
+
+// out = y + h f
+template <typename Real>
+__global__ void __launch_bounds__(256) crd_axpy_kernel(const Real *__restrict__ y, const Real *__restrict__ f, Real h, Real *__restrict__ out, size_t n)
+{
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) out[q] = fmadd(h, f[q], y[q]);
+}
+
+// partials[block] (+)= sum over the block's elements of (((f2 - f0) / h) / (rtol |y| + atol))^2: one partial per block, blocks
+// stride the field in a fixed pattern and the partials are added in block order afterwards, so the norm is reproducible
+constexpr int kNormBlocks = 256;
+template <typename Real>
+__global__ void __launch_bounds__(256) crd_ydd_sumsq_kernel(const Real *__restrict__ f2, const Real *__restrict__ f0, const Real *__restrict__ y, size_t n, double inv_h,
+                                                            double rtol, double atol, double *__restrict__ partials, int accumulate)
+{
+	__shared__ double part[256];
+	double sum = 0.0;
+	for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < n; q += (size_t)gridDim.x * blockDim.x) {
+		const double e = ((double)f2[q] - (double)f0[q]) * inv_h / (rtol * fabs((double)y[q]) + atol);
+		sum = fma(e, e, sum);
+	}
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	for (int w = 128; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) partials[blockIdx.x] = (accumulate ? partials[blockIdx.x] : 0.0) + part[0];
+}
+
+__global__ void __launch_bounds__(kNormBlocks) crd_sum_blocks_kernel(const double *__restrict__ partials, double *__restrict__ out)
+{
+	__shared__ double part[kNormBlocks];
+	part[threadIdx.x] = partials[threadIdx.x];
+	__syncthreads();
+	for (int w = kNormBlocks / 2; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *out = part[0];
+}
+
+template <typename Real>
+hipError_t launch_hin_ops_t(int op, Planes y, Planes a, Planes b, int nx, int nyl, double h, double rtol, double atol, double *partials, double *out, hipStream_t st)
+{
+	const size_t n = (size_t)nx * (size_t)nyl;
+	const int g = grid_for(n);
+	void *yy[2] = {y.u, y.v}, *aa[2] = {a.u, a.v}, *bb[2] = {b.u, b.v};
+	for (int f = 0; f < 2; f++) {
+		const Real *yp = row0<Real>(yy[f], nx), *ap = row0<Real>(aa[f], nx);
+		Real *bp = row0<Real>(bb[f], nx);
+		if (op == 0) crd_hin_bound_kernel<Real><<<g, 256, 0, st>>>(yp, ap, n, rtol, atol, out);
+		else if (op == 1) crd_axpy_kernel<Real><<<g, 256, 0, st>>>(yp, ap, (Real)h, bp, n);
+		else crd_ydd_sumsq_kernel<Real><<<kNormBlocks, 256, 0, st>>>(bp, ap, yp, n, 1.0 / h, rtol, atol, partials, f);
+	}
+	if (op == 2) crd_sum_blocks_kernel<<<1, kNormBlocks, 0, st>>>(partials, out);
+	return launch_status();
+}
+
+hipError_t launch_hin_bound(int precision, Planes y, Planes f, int nx, int nyl, double rtol, double atol, double *out_dev, hipStream_t s)
+{
+	clear_launch_status();
+	hipError_t e = hipMemsetAsync(out_dev, 0, sizeof(double), s);
+	if (e != hipSuccess) return e;
+	return precision == CRD_PRECISION_F64 ? launch_hin_ops_t<double>(0, y, f, Planes{nullptr, nullptr}, nx, nyl, 0.0, rtol, atol, nullptr, out_dev, s)
+	                                      : launch_hin_ops_t<float>(0, y, f, Planes{nullptr, nullptr}, nx, nyl, 0.0, rtol, atol, nullptr, out_dev, s);
+}
+
+hipError_t launch_axpy_planes(int precision, Planes y, Planes f, double h, Planes out, int nx, int nyl, hipStream_t s)
+{
+	clear_launch_status();
+	return precision == CRD_PRECISION_F64 ? launch_hin_ops_t<double>(1, y, f, out, nx, nyl, h, 0.0, 0.0, nullptr, nullptr, s)
+	                                      : launch_hin_ops_t<float>(1, y, f, out, nx, nyl, h, 0.0, 0.0, nullptr, nullptr, s);
+}
+
+hipError_t launch_ydd_sumsq(int precision, Planes y, Planes f0, Planes f2, double h, double rtol, double atol, int nx, int nyl, double *partials_dev, double *out_dev,
+                            hipStream_t s)
+{
+	clear_launch_status();
+	return precision == CRD_PRECISION_F64 ? launch_hin_ops_t<double>(2, y, f0, f2, nx, nyl, h, rtol, atol, partials_dev, out_dev, s)
+	                                      : launch_hin_ops_t<float>(2, y, f0, f2, nx, nyl, h, rtol, atol, partials_dev, out_dev, s);
+}
+
 hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s)
 {
 	clear_launch_status();

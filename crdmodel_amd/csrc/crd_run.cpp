@@ -2,7 +2,8 @@
 // text files the reference's Python plotting / torus-mapping utilities read.  It replaces main() of the four
 // reference programs (src/FHNmodel_torus.cpp:148-497 and siblings); invoked through one of the alias names
 // FHNmodel_torus / FHNmodel_flat / GoldbeterModel_torus / GoldbeterModel_flat it takes exactly one argument, like
-// they do.  Time integration is fixed-step RK4 on the GPU (libcrd) instead of adaptive ARKode.
+// they do.  Time integration is fixed-step RK4 on the GPU (libcrd) by default; --adaptive runs the reference's integrator,
+// ARKode's default explicit pair and controller restated (CRD_ADAPT_ARKODE), --adaptive-rk43 the RK4(3) pair of earlier rounds.
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -42,7 +43,7 @@ struct Options {
 	} else {
 		std::cerr << "Usage: " << argv0
 		          << " --model fhn|goldbeter --surface torus|flat [--gpus G] [--devices D] [--dt DT] [--stepper auto|staged|fused]\n"
-		             "       [--precision 64|32] [--adaptive|--fixed] [--binary|--binary-only] [--ref-steady-state] [--outdir DIR] [--quiet]\n"
+		             "       [--precision 64|32] [--adaptive|--adaptive-rk43|--fixed] [--binary|--binary-only] [--ref-steady-state] [--outdir DIR] [--quiet]\n"
 		             "       <Config file path>\n";
 	}
 	std::exit(EXIT_FAILURE);
@@ -83,7 +84,8 @@ void banner(const crd_run_config &cfg, const crd_grid &g, int n_slabs, int64_t n
 	std::cout << "   Wavelength = " << cfg.wave_length * 100 << "%\n";
 	std::cout << "   Wavewidth = " << cfg.wave_width * 100 << "%\n";
 	if (fhn && torus) std::cout << "   Wave inside = " << cfg.wave_inside << "\n";
-	if (cfg.adaptive) std::cout << "   integrator = adaptive RK4(3) on GPU\n   rtol = " << cfg.rtol << "\n   atol = " << cfg.atol << "\n";
+	if (cfg.adaptive == 2) std::cout << "   integrator = adaptive RK4(3) on GPU\n   rtol = " << cfg.rtol << "\n   atol = " << cfg.atol << "\n";
+	else if (cfg.adaptive) std::cout << "   integrator = ARKode-style ERK on GPU (Zonneveld 5(3)4, PID controller)\n   rtol = " << cfg.rtol << "\n   atol = " << cfg.atol << "\n";
 	else std::cout << "   integrator = classical RK4 on GPU, dt = " << dt << " (" << steps_per_output << " steps per output)\n";
 	if (!fhn && p.just_diffusion == 1) {
 		std::cout << "   Diffusion Only\n\n";
@@ -171,6 +173,7 @@ int main(int argc, char *argv[])
 			else if (s == "--outdir") o.outdir = next();
 			else if (s == "--quiet") o.quiet = true;
 			else if (s == "--adaptive") o.adaptive = 1;
+			else if (s == "--adaptive-rk43") o.adaptive = 2;
 			else if (s == "--fixed") o.adaptive = 0;
 			else if (s == "--binary") o.binary = true;
 			else if (s == "--binary-only") o.binary = o.binary_only = true;
@@ -333,7 +336,8 @@ int main(int argc, char *argv[])
 			crd_adaptive_defaults(&ao);
 			ao.rtol = cfg.rtol;
 			ao.atol = cfg.atol;
-			ao.h0 = adaptive_h;
+			ao.method = cfg.adaptive == 2 ? CRD_ADAPT_RK43 : CRD_ADAPT_ARKODE;
+			ao.h0 = cfg.adaptive == 2 ? adaptive_h : 0.0;  // (the ARKode-style controller keeps its own memory in the contexts; first step: arkHin)
 			ao.dense_output = 1;  // ARK_NORMAL: output times do not shorten steps, the row written is the interpolant at tout
 			crd_adaptive_stats as;
 			rc = crd_group_integrate_adaptive(ctx.data(), G, t, (iout + 1 == Nt) ? cfg.t_final : (iout + 1) * dTout, &ao, &as);

@@ -239,6 +239,7 @@ FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int ds
 	call.dt = dt;
 	const double cs[4] = {0.0, 0.5, 0.5, 1.0};
 	for (int k = 0; k < 4; k++) call.absorb[k] = absorbing(c, t + cs[k] * dt) ? 1 : 0;
+	call.absorb[4] = call.absorb[3];  // (the embedded pairs' fifth stage: set by the adaptive integrator)
 	call.y0 = c->planes(src);
 	call.yout = c->planes(dst);
 	call.plan = const_cast<FusedPlan *>(&c->plan);
@@ -252,7 +253,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 	if (nsteps < 0 || !(dt > 0.0) || !std::isfinite(t0)) return fail(lead, CRD_EINVAL, "bad t0 / dt / nsteps");
 	const int stepper = resolve_stepper(lead);
 	if (stepper < 0) return fail(lead, CRD_EINVAL, "fused stepper not available for this configuration");
-	for (int k = 0; k < n; k++) cs[k]->dense.pending = false;  // stepping on from the state handed back, not from the integrator's internal one
+	for (int k = 0; k < n; k++) cs[k]->dense.pending = cs[k]->ark.live = false;  // stepping on from the state handed back, not from the integrator's internal one
 	if (stepper != CRD_STEPPER_FUSED)
 		for (int k = 0; k < n; k++) cs[k]->cycle_pos = -1;  // the staged stepper keeps one ghost row of one field current, not the deep halo
 	for (int k = 0; k < n; k++)
@@ -459,8 +460,8 @@ int crd_adaptive_defaults(crd_adaptive_options *o)
 	o->shrink = 0.1;
 	o->max_steps = 200000;  // :372
 	o->h_max = 0.0;         // automatic: the diffusion-stability bound
-	o->dense_output = 0;
-	o->reserved = 0;
+	o->dense_output = 1;    // ARK_NORMAL, :423
+	o->method = CRD_ADAPT_ARKODE;  // the reference's integrator: ARKodeInit(mem, f, NULL, ...) = default explicit table, order 4 (:362)
 	return CRD_OK;
 }
 
@@ -484,6 +485,112 @@ static int rhs_on_planes(crd_ctx *const *cs, int n, double t, int src, int dst)
 	return CRD_OK;
 }
 
+// One scalar per slab (left in c->scalar_dev by work already enqueued on the compute streams) combined over the run: the sum or
+// the maximum, identical on every rank (RCCL: ncclAllReduce; LOCAL groups: added / compared on the host in slab order).
+static int collect_scalar(crd_ctx *const *cs, int n, bool take_max, double *out)
+{
+	double acc = 0.0;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		if (c->halo == CRD_HALO_RCCL) NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev, c->scalar_dev, 1, ncclDouble, take_max ? ncclMax : ncclSum, c->nccl, c->compute));
+		double part = 0.0;
+		HIP_TRY(c, hipMemcpyAsync(&part, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
+		HIP_TRY(c, hipStreamSynchronize(c->compute));
+		if (take_max) acc = (part > acc || part != part) ? part : acc;
+		else acc += part;
+	}
+	*out = acc;
+	return CRD_OK;
+}
+
+// ARKode's step-size controller (CRD_ADAPT_ARKODE), restated from its documentation; oracle/arkode_erk.py has the same rules
+// with the same names, and the tests compare the two attempt by attempt.
+namespace arkode {
+constexpr double kK1 = 0.58, kK2 = 0.21, kK3 = 0.1;  // ARK_ADAPT_PID gains
+constexpr int kEmbeddingOrder = 3;                   // Zonneveld 5(3)4; "pq = 0": the embedding's order enters the exponents
+constexpr double kEtamx1 = 10000.0, kEtamxf = 0.3;   // growth bound of the very first step; bound from the second failure of a step on
+constexpr int kSmallNef = 2, kMaxNef = 7;
+constexpr double kLbound = 1.0, kUbound = 1.5, kOnePsm = 1.000001, kOneMsm = 0.999999;  // no change of h for lbound <= eta <= ubound
+constexpr double kTiny = 1.0e-10, kUround = 2.220446049250313e-16;
+constexpr double kH0LbFactor = 100.0, kH0UbFactor = 0.1, kH0Bias = 0.5;
+constexpr int kH0Iters = 4;
+
+// arkAdapt with the PID method and no explicit-stability function: eta = h_new / h.  e = (this step's biased error, the previous
+// accepted step's, the one before that).
+double pid_eta(double h, const double e[3], double etamax, double safety, double etamin, double h_cap)
+{
+	const double e1 = std::fmax(e[0], kTiny), e2 = std::fmax(e[1], kTiny), e3 = std::fmax(e[2], kTiny);
+	double h_acc = h * std::pow(e1, -kK1 / kEmbeddingOrder) * std::pow(e2, kK2 / kEmbeddingOrder) * std::pow(e3, -kK3 / kEmbeddingOrder);
+	h_acc *= safety;
+	h_acc = std::fmin(std::fabs(h_acc), std::fabs(etamax * h));
+	h_acc = std::fmax(std::fabs(h_acc), std::fabs(etamin * h));
+	if (std::fabs(h_acc) > std::fabs(h * kLbound * kOneMsm) && std::fabs(h_acc) < std::fabs(h * kUbound * kOnePsm)) h_acc = h;
+	double eta = h_acc / h;
+	if (std::isfinite(h_cap)) eta /= std::fmax(1.0, std::fabs(h) * eta / h_cap);  // hmax_inv
+	return eta;
+}
+}  // namespace arkode
+
+// arkHin: ARKode's estimate of the first step from y'' along a forward Euler trial step, on the planes: f0 -> SB, trial state ->
+// SA, f(trial) -> ACC (all three are scratch on a fresh state).
+static int arkode_initial_step(crd_ctx *const *cs, int n, double t0, double tout, int cur, const crd_adaptive_options &o, double n_components, double *h0)
+{
+	using namespace arkode;
+	crd_ctx *lead = cs[0];
+	const double tdist = std::fabs(tout - t0), tround = kUround * std::fmax(std::fabs(t0), std::fabs(tout));
+	if (tdist < 2.0 * tround) return fail(lead, CRD_EINVAL, "adaptive integration: tout too close to t0 to estimate a first step");
+	const double hlb = kH0LbFactor * tround;
+	if (int rc = rhs_on_planes(cs, n, t0, cur, crd_ctx::SB)) return rc;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		HIP_TRY(c, launch_hin_bound(c->p.precision, c->planes(cur), c->planes(crd_ctx::SB), c->nx, c->nyl, o.rtol, o.atol, c->scalar_dev, c->compute));
+	}
+	double hub_inv = 0.0;
+	if (int rc = collect_scalar(cs, n, true, &hub_inv)) return rc;
+	double hub = kH0UbFactor * tdist;
+	if (hub * hub_inv > 1.0) hub = 1.0 / hub_inv;
+	double hg = std::sqrt(hlb * hub);
+	if (hub < hlb) {
+		*h0 = hg;
+		return CRD_OK;
+	}
+	bool hnew_ok = false;
+	double hnew = hg;
+	for (int count = 1; count <= kH0Iters; count++) {
+		for (int k = 0; k < n; k++) {
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			HIP_TRY(c, launch_axpy_planes(c->p.precision, c->planes(cur), c->planes(crd_ctx::SB), hg, c->planes(crd_ctx::SA), c->nx, c->nyl, c->compute));
+		}
+		if (int rc = rhs_on_planes(cs, n, t0 + hg, crd_ctx::SA, crd_ctx::ACC)) return rc;
+		for (int k = 0; k < n; k++) {
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			HIP_TRY(c, launch_ydd_sumsq(c->p.precision, c->planes(cur), c->planes(crd_ctx::SB), c->planes(crd_ctx::ACC), hg, o.rtol, o.atol, c->nx, c->nyl, c->err_partials,
+			                            c->scalar_dev, c->compute));
+		}
+		double sum = 0.0;
+		if (int rc = collect_scalar(cs, n, false, &sum)) return rc;
+		const double yddnrm = std::sqrt(sum / n_components);
+		if (hnew_ok || count == kH0Iters) {
+			hnew = hg;
+			break;
+		}
+		hnew = (yddnrm * hub * hub > 2.0) ? std::sqrt(2.0 / yddnrm) : std::sqrt(hg * hub);
+		const double hrat = hnew / hg;
+		if (hrat > 0.5 && hrat < 2.0) hnew_ok = true;
+		if (count > 1 && hrat > 2.0) {
+			hnew = hg;
+			hnew_ok = true;
+		}
+		hg = hnew;
+	}
+	*h0 = std::fmin(std::fmax(kH0Bias * hnew, hlb), hub);
+	return CRD_OK;
+}
+
 // Error-controlled integration of all slabs of a run (n = 1: a single-slab or RCCL context; n > 1: a LOCAL group).
 static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double tout, const crd_adaptive_options *opt_in, crd_adaptive_stats *stats)
 {
@@ -493,16 +600,18 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	crd_adaptive_defaults(&o);
 	if (opt_in) o = *opt_in;
 	if (!(o.rtol >= 0.0) || !(o.atol >= 0.0) || !(o.rtol + o.atol > 0.0) || !(o.safety > 0.0) || !(o.bias > 0.0) || !(o.growth >= 1.0) ||
-	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || std::isnan(o.h_max) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0)
+	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || std::isnan(o.h_max) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0 ||
+	    (o.method != CRD_ADAPT_RK43 && o.method != CRD_ADAPT_ARKODE))
 		return fail(lead, CRD_EINVAL, "bad adaptive options / time interval");
 	const bool multi = lead->halo != CRD_HALO_SELF;
-	const bool dense = o.dense_output != 0;
+	const bool arkode_method = o.method == CRD_ADAPT_ARKODE;
+	const bool dense = o.dense_output != 0 || arkode_method;  // ARKode's ARK_NORMAL never shortens a step for an output time
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (!fused_step_supported(c->p.precision, c->desc)) return fail(lead, CRD_EINVAL, "slab too small for the fused step kernel");
 		if (int rc = set_device(c)) return rc;
 		if (!c->err_partials) {
-			c->err_capacity = fused_max_items(c->desc);
+			c->err_capacity = std::max(fused_max_items(c->desc), 256);  // (256: the block partials of the initial-step norm)
 			HIP_TRY(c, hipMalloc((void **)&c->err_partials, sizeof(double) * (size_t)c->err_capacity));
 		}
 		if (dense)
@@ -515,7 +624,6 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	for (int k = 0; k < n; k++) cs[k]->cycle_pos = -1;  // the integrator exchanges as it needs; a fixed-step call afterwards starts afresh
 	crd_adaptive_stats st{};
 	const double h_cap = o.h_max > 0.0 ? o.h_max : (o.h_max == 0.0 ? crd_stable_dt(&lead->p) : INFINITY);
-	double h = std::fmin(o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&lead->p), h_cap);
 	const double n_components = 2.0 * (double)lead->g.nx * (double)lead->g.ny;  // WRMS norm over the whole grid
 	constexpr int kEmbedHalo = kStepHalo + 1;                                     // the fifth stage reads one more row
 
@@ -523,7 +631,9 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	double t = t0;
 	int cur = crd_ctx::Y, spare = crd_ctx::SA, third = dense ? crd_ctx::OUT : -1, prev = -1;
 	double t_prev = t0;
-	const bool resume = dense && lead->dense.pending && t0 == lead->dense.t_out;
+	// A call continues the previous one when it starts at the output time that one handed back and nothing has replaced the state
+	// since (ARKode keeps its memory between ARKode() calls the same way); the ARKode-style controller also needs its own memory.
+	const bool resume = dense && lead->dense.pending && t0 == lead->dense.t_out && (!arkode_method || lead->ark.live);
 	for (int k = 0; k < n; k++)
 		if (!resume) cs[k]->dense.pending = false;
 	auto hand_back = [&](double theta, double hstep) -> int {  // interpolant of step prev -> cur at t_prev + theta hstep into plane Y, planes re-labelled
@@ -544,6 +654,8 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 		}
 		return CRD_OK;
 	};
+	auto &A = lead->ark;  // (every context of the run gets a copy at the end)
+	double h = 0.0;
 	if (resume) {
 		st.t_internal = lead->dense.t_np1;
 		if (tout <= lead->dense.t_np1) {  // still inside the step the integrator has already taken: interpolate again
@@ -553,7 +665,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			if (int rc = hand_back((tout - lead->dense.t_n) / hstep, hstep)) return rc;
 			for (int k = 0; k < n; k++) cs[k]->dense.t_out = tout;
 			st.t = tout;
-			st.h_next = h;
+			st.h_next = arkode_method ? A.hprime : std::fmin(o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&lead->p), h_cap);
 			if (stats) *stats = st;
 			return CRD_OK;
 		}
@@ -562,9 +674,118 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 		spare = crd_ctx::OUT;  // y_n of the finished step: free
 		third = crd_ctx::Y;    // the interpolant handed back last time: free
 	}
+	if (arkode_method) {
+		if (!resume) {  // a fresh state: ARKodeInit
+			A.live = false;
+			A.nst = 0;
+			A.tn = t0;
+			A.eta = 1.0;
+			A.etamax = arkode::kEtamx1;
+			A.ehist[0] = A.ehist[1] = A.ehist[2] = 1.0;
+			A.h = o.h0;
+			if (!(A.h > 0.0) && tout > t0)
+				if (int rc = arkode_initial_step(cs, n, t0, tout, cur, o, n_components, &A.h)) return rc;
+			A.h = std::fmin(A.h, h_cap);
+			A.hprime = A.h;
+		}
+		h = A.h;
+	} else {
+		h = std::fmin(o.h0 > 0.0 ? o.h0 : 0.8 * crd_stable_dt(&lead->p), h_cap);
+	}
+	st.h_first = (arkode_method && A.nst > 0 && A.hprime != A.h) ? A.h * A.eta : h;
+
+	// One attempt of size hh from plane `cur` into plane `dst`: *sum = the weighted square sum of the error estimate over the grid.
+	auto attempt = [&](double hh, int dst, double *sum) -> int {
+		if (multi)  // every attempt starts from freshly exchanged ghost rows of the current state (no overlap: the host waits for the norm anyway)
+			if (int rc = prime_halo(cs, n, cur, kEmbedHalo, true)) return rc;
+		for (int k = 0; k < n; k++) {
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			FusedCall call = make_fused_call(c, t, hh, cur, dst);
+			call.embed = arkode_method ? 2 : 1;
+			call.absorb[4] = arkode_method ? (absorbing(c, t + 0.75 * hh) ? 1 : 0) : call.absorb[3];  // the fifth stage's time: t + 3/4 h (Zonneveld) / t + h
+			call.plan = arkode_method ? &c->plan_arkode : &c->plan_embed;
+			call.rtol = o.rtol;
+			call.atol = o.atol;
+			call.err_partials = c->err_partials;
+			call.err_capacity = c->err_capacity;
+			call.err_sum = c->scalar_dev;
+			if (multi) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
+		}
+		return collect_scalar(cs, n, false, sum);  // (RCCL: every rank gets the same bits, hence takes the same decision)
+	};
+	auto accept_planes = [&](int dst) {  // rotate: the old state becomes y_n (kept for the interpolant), the old y_n / scratch becomes the next target
+		const int old_cur = cur;
+		cur = dst;
+		if (dense) {
+			spare = (prev >= 0) ? prev : third;
+			if (prev < 0) third = -1;
+			prev = old_cur;
+		} else {
+			spare = old_cur;
+		}
+	};
+
 	bool after_reject = false;
 	int rc = CRD_OK;
-	while (t < tout) {
+	int64_t steps_this_call = 0;
+	while (t < tout && rc == CRD_OK && arkode_method) {
+		// ---- CRD_ADAPT_ARKODE: one step = attempts until the error test passes (arkStep), then arkPrepareNextStep / arkCompleteStep ----
+		if (steps_this_call >= o.max_steps) {
+			rc = fail(lead, CRD_ESTATE, "adaptive integration: max_steps steps taken before reaching tout (ARK_TOO_MUCH_WORK)");
+			break;
+		}
+		if (A.nst > 0 && A.hprime != A.h) A.h *= A.eta;
+		if (!(A.h > 1e-14 * std::fmax(std::fabs(t), 1e-300)) && !(t == 0.0 && A.h > 0.0)) {
+			rc = fail(lead, CRD_ESTATE, "adaptive integration: step size underflow");
+			break;
+		}
+		const int dst = spare;
+		double dsm = 0.0;
+		for (int nef = 0;;) {
+			double sum = 0.0;
+			if ((rc = attempt(A.h, dst, &sum))) break;
+			dsm = std::sqrt(sum / n_components);
+			st.err_last = dsm;
+			if (dsm <= 1.0) break;  // (a NaN fails the test)
+			nef++;
+			st.rejected++;
+			if (nef == arkode::kMaxNef) {
+				rc = fail(lead, CRD_ESTATE, "adaptive integration: the error test failed 7 times on one step (ARK_ERR_FAILURE)");
+				break;
+			}
+			A.etamax = 1.0;  // no growth for the rest of this step, and none after it
+			const double e[3] = {std::isfinite(dsm) ? dsm * o.bias : 1e300, A.ehist[0], A.ehist[1]};
+			double eta = arkode::pid_eta(A.h, e, A.etamax, o.safety, o.shrink, h_cap);
+			if (nef >= arkode::kSmallNef) eta = std::fmin(eta, arkode::kEtamxf);
+			A.h *= eta;
+		}
+		if (rc != CRD_OK) break;
+		A.ehist[2] = A.ehist[1];
+		A.ehist[1] = A.ehist[0];
+		A.ehist[0] = dsm * o.bias;
+		if (A.etamax == 1.0) {  // the step failed its test at least once: keep its size for the next one
+			A.hprime = A.h;
+			A.eta = 1.0;
+		} else {
+			A.eta = arkode::pid_eta(A.h, A.ehist, A.etamax, o.safety, o.shrink, h_cap);
+			A.hprime = A.h * A.eta;
+		}
+		A.etamax = o.growth;
+		t_prev = t;
+		t += A.h;
+		A.tn = t;
+		A.nst++;
+		steps_this_call++;
+		accept_planes(dst);
+		st.accepted++;
+		st.h_last = A.h;
+		st.h_min = (st.h_min == 0.0) ? A.h : std::fmin(st.h_min, A.h);
+		st.h_max = std::fmax(st.h_max, A.h);
+	}
+	while (t < tout && rc == CRD_OK && !arkode_method) {
+		// ---- CRD_ADAPT_RK43: the embedded pair and I-controller of rounds 1-2 ----
 		if (st.accepted + st.rejected >= o.max_steps) {
 			rc = fail(lead, CRD_ESTATE, "adaptive integration: max_steps attempts taken before reaching tout");
 			break;
@@ -580,34 +801,8 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			break;
 		}
 		const int dst = spare;
-		if (multi)  // every attempt starts from freshly exchanged ghost rows of the current state (no overlap: the host waits for the norm anyway)
-			if ((rc = prime_halo(cs, n, cur, kEmbedHalo, true))) break;
 		double sum = 0.0;
-		for (int k = 0; k < n && rc == CRD_OK; k++) {
-			crd_ctx *c = cs[k];
-			if ((rc = set_device(c))) break;
-			FusedCall call = make_fused_call(c, t, hh, cur, dst);
-			call.embed = 1;
-			call.plan = &c->plan_embed;
-			call.rtol = o.rtol;
-			call.atol = o.atol;
-			call.err_partials = c->err_partials;
-			call.err_capacity = c->err_capacity;
-			call.err_sum = c->scalar_dev;
-			if (multi) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
-			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
-			if (c->halo == CRD_HALO_RCCL)  // every rank gets the same bits, hence takes the same decision
-				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev, c->scalar_dev, 1, ncclDouble, ncclSum, c->nccl, c->compute));
-		}
-		for (int k = 0; k < n && rc == CRD_OK; k++) {  // LOCAL groups: add the slabs' sums in slab order
-			crd_ctx *c = cs[k];
-			if ((rc = set_device(c))) break;
-			double part = 0.0;
-			HIP_TRY(c, hipMemcpyAsync(&part, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
-			HIP_TRY(c, hipStreamSynchronize(c->compute));
-			sum += part;
-		}
-		if (rc != CRD_OK) break;
+		if ((rc = attempt(hh, dst, &sum))) break;
 		const double err = o.bias * std::sqrt(sum / n_components);
 		st.err_last = err;
 		double eta;
@@ -617,16 +812,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 		if (err <= 1.0) {
 			t_prev = t;
 			t = clipped ? tout : t + hh;
-			// rotate: the old state becomes y_n (kept for the interpolant), the old y_n / scratch becomes the next target
-			const int old_cur = cur;
-			cur = dst;
-			if (dense) {
-				spare = (prev >= 0) ? prev : third;
-				if (prev < 0) third = -1;
-				prev = old_cur;
-			} else {
-				spare = old_cur;
-			}
+			accept_planes(dst);
 			st.accepted++;
 			if (after_reject) eta = std::fmin(eta, 1.0);  // no growth right after a rejection
 			after_reject = false;
@@ -667,6 +853,11 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			cs[k]->dense.pending = false;
 		}
 	}
+	if (arkode_method) {
+		A.live = rc == CRD_OK && lead->dense.pending;
+		for (int k = 1; k < n; k++) cs[k]->ark = A;
+		h = A.hprime;
+	}
 	st.t = t;
 	st.h_next = h;
 	if (stats) *stats = st;
@@ -703,7 +894,7 @@ int crd_plan_launches(crd_ctx *c)
 	// One step of the resident state into the scratch planes, discarded: its first launch is where the plan is measured.  The
 	// state itself (plane Y) is only read; ghost rows may be stale, which only matters to results nobody keeps.
 	FusedCall call = make_fused_call(c, 0.0, 1e-9 * crd_stable_dt(&c->p), crd_ctx::Y, crd_ctx::SA);
-	for (int k = 0; k < 4; k++) call.absorb[k] = 0;
+	for (int k = 0; k < 5; k++) call.absorb[k] = 0;
 	const int lo = c->halo == CRD_HALO_SELF ? 0 : kStepHalo, hi = c->halo == CRD_HALO_SELF ? c->nyl : c->nyl - kStepHalo;
 	HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, lo, hi, 0, 0, c->compute));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));

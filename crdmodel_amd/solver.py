@@ -247,7 +247,9 @@ class Slab:
         return ms.value, kms.value, lps.value
 
     def integrate_adaptive(self, t0, tout, **options):
-        """Error-controlled RK4(3) from t0 to tout; options override crd_adaptive_defaults (rtol, atol, h0, ...).  Returns stats."""
+        """Error-controlled integration from t0 to tout; options override crd_adaptive_defaults (rtol, atol, h0, method, ...): by
+        default the reference's integrator (ARKode's Zonneveld 5(3)4 pair + PID controller, ARK_NORMAL output); method=0 with
+        dense_output=0/1 is the RK4(3) pair of earlier rounds.  Returns stats."""
         opt, st = _adaptive_options(options), capi.AdaptiveStats()
         rc = lib().crd_integrate_adaptive(self._h, t0, tout, C.byref(opt), C.byref(st))
         return _adaptive_result(rc, st, "crd_integrate_adaptive", self._h)

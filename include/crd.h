@@ -98,7 +98,8 @@ typedef struct crd_run_config {
 	double dt_safety;         /* [Solver] dtSafety, default 0.8 */
 	int32_t n_gpus;           /* [Solver] gpus, default 1 */
 	int32_t stepper;          /* [Solver] stepper: CRD_STEPPER_* */
-	int32_t adaptive;         /* [Solver] adaptive = 1: error-controlled steps (crd_integrate_adaptive) instead of a fixed dt */
+	int32_t adaptive;         /* [Solver] adaptive: 0 = fixed dt; 1 = error-controlled steps with ARKode's default explicit pair and controller
+	                           * (CRD_ADAPT_ARKODE: the reference's integrator); 2 = the RK4(3) pair of earlier rounds (CRD_ADAPT_RK43) */
 	int32_t steady_state_decimals; /* [Solver] steadyStateDigits (crd_run --ref-steady-state = 8): 0 = the exact Goldbeter fixed point;
 	                                * n > 0 = that fixed point as the reference receives it, through numpy's print of a one-element
 	                                * array (n digits behind the decimal point; numpy's default is 8) and fscanf
@@ -288,6 +289,18 @@ int crd_synchronize(crd_ctx *ctx);
  * every attempt and reduce the norm over the ring (ncclAllReduce; LOCAL groups add the slabs' sums on the host in slab
  * order), so every rank takes the same decisions.  h0 = 0 starts from the diffusion-stability step; by default steps are
  * also capped at that bound (h_max = 0), which removes the reject / regrow cycle of a stability-limited explicit method. */
+/* Which embedded pair and controller crd_integrate_adaptive runs. */
+enum {
+	CRD_ADAPT_RK43 = 0,   /* rounds 1-2: classical RK4 + k5 = f(t+h, y_new) as third-order embedding, I-controller; steps may be shortened to
+	                       * land on tout (dense_output = 0) */
+	CRD_ADAPT_ARKODE = 1  /* the integrator the reference uses (src/FHNmodel_torus.cpp:356-372): SUNDIALS ARKode's default explicit
+	                       * fourth-order table, Zonneveld 5(3)4 -- whose propagated solution is classical RK4 too -- with ARKode's PID
+	                       * controller, its safeguards, its initial-step estimate and ARK_NORMAL output (dense_output is taken as 1).
+	                       * Restated from ARKode's published documentation (the library is not in the reference tree): the algorithm
+	                       * and every constant are written out in oracle/arkode_erk.py.  The controller's memory (step, error history)
+	                       * lives in the context and carries from call to call like ARKode's does, until the state is replaced. */
+};
+
 typedef struct crd_adaptive_options {
 	double rtol, atol;      /* 1e-5, 1e-10 in the reference (src/FHNmodel_torus.cpp:197-198) */
 	double h0;              /* first step; 0 = automatic */
@@ -300,7 +313,11 @@ typedef struct crd_adaptive_options {
 	                         * diffusion operator, crd_stable_dt (what ARKodeSetStabilityFn is for: beyond it the error test
 	                         * only finds out by failing); < 0 = no cap, error control alone (ARKode's default) */
 	int32_t dense_output;   /* 0: shorten the last step to hit tout; 1: ARK_NORMAL -- overshoot and interpolate back (see above) */
-	int32_t reserved;
+	int32_t method;         /* CRD_ADAPT_*; crd_adaptive_defaults: CRD_ADAPT_ARKODE with dense_output = 1.  Under CRD_ADAPT_ARKODE h0 = 0 means
+	                         * ARKode's own estimate (arkHin) on a fresh state, safety / bias / growth / shrink are ARKode's constants of the
+	                         * same names (shrink = ETAMIN), and the remaining ones (PID gains 0.58 / 0.21 / 0.1 over the embedding order 3,
+	                         * first-step growth 10000, 0.3 after repeated failures, at most 7 failures per step, no change of h for a
+	                         * suggested growth within [1, 1.5]) are fixed */
 } crd_adaptive_options;
 typedef struct crd_adaptive_stats {
 	int64_t accepted, rejected;
@@ -310,6 +327,7 @@ typedef struct crd_adaptive_stats {
 	double err_last;        /* bias * WRMS norm of the last attempt */
 	double t;               /* time of the state handed back (== tout on success) */
 	double t_internal;      /* time the integrator itself has reached: == t without dense output, >= t with it */
+	double h_first;         /* size of the first step this call attempted (on a fresh state under CRD_ADAPT_ARKODE: the arkHin estimate) */
 } crd_adaptive_stats;
 int crd_adaptive_defaults(crd_adaptive_options *opt);
 int crd_integrate_adaptive(crd_ctx *ctx, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats);

@@ -64,28 +64,31 @@ def test_driver_writes_reference_format(gpu_device, tmp_path, argv):
 
 
 def test_driver_adaptive_mode(gpu_device, tmp_path):
-    """`--adaptive`: one error-controlled integration per output interval (as the reference calls ARKode once per output, in
-    ARK_NORMAL mode: output times do not shorten steps, the rows written are interpolants), the controller's step carried from
-    interval to interval; checked against the CPU restatement of the same controller and interpolant."""
+    """`--adaptive`: one error-controlled integration per output interval, as the reference calls ARKode once per output in
+    ARK_NORMAL mode (output times do not shorten steps, the rows written are interpolants, the controller's memory carries
+    from interval to interval), with ARKode's default explicit pair and controller (CRD_ADAPT_ARKODE) -- checked against the
+    oracle's restatement of that published algorithm; `--adaptive-rk43`: the RK4(3) pair of earlier rounds against its own
+    restatement."""
+    from oracle import arkode_erk as ark
+
     cfg = crd.load_ini(INI, "fhn", "torus")
-    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--adaptive", INI], cwd=tmp_path, capture_output=True,
-                       text=True, timeout=300)
-    assert r.returncode == 0, r.stderr
-    assert "integrator = adaptive RK4(3) on GPU" in r.stdout and "rtol = 1e-05" in r.stdout and "steps = " in r.stdout
     p = cfg.params
     g = crd.grid_of(p)
     op = co.make_problem(co.FHN, co.TORUS, g.nx, p.surface_length, p.surface_width, p.diffusion, p.beta, ny=p.ny, t_boundary=p.t_boundary)
-    y = co.initial_conditions(op, cfg.wave_length, cfg.wave_width, cfg.wave_inside, 0)
-    frames, h, dense = [y], 0.8 * crd.stable_dt(p), {}
+    y0 = co.initial_conditions(op, cfg.wave_length, cfg.wave_width, cfg.wave_inside, 0)
     d_tout = cfg.t_final / cfg.output_timestep
-    for k in range(cfg.output_timestep):
-        y, st = co.integrate_adaptive(op, y, k * d_tout, cfg.t_final if k + 1 == cfg.output_timestep else (k + 1) * d_tout, h, h_max=crd.stable_dt(p),
-                                      dense=dense)
-        h = st["h_next"]
-        frames.append(y)
-    want = np.stack(frames)
+    touts = [cfg.t_final if k + 1 == cfg.output_timestep else (k + 1) * d_tout for k in range(cfg.output_timestep)]
+
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--adaptive", INI], cwd=tmp_path, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "integrator = ARKode-style ERK on GPU (Zonneveld 5(3)4, PID controller)" in r.stdout and "rtol = 1e-05" in r.stdout and "steps = " in r.stdout
+    integ = ark.ArkodeErk(op, 0.0, y0, h_max=crd.stable_dt(p))
+    want = np.stack([y0] + [integ.evolve(t)[0] for t in touts])
     u, _ = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "u")
     assert rel_err(u, want[..., 0]) <= 1e-9
+    m = re.search(r"steps = (\d+) \(\+(\d+) rejected\)", r.stdout)
+    assert m and (int(m.group(1)), int(m.group(2))) == (integ.nst, integ.netf)
     # two slabs: same controller, halos per attempt, norm summed over the slabs -> the same files up to round-off
     out2 = tmp_path / "two"
     out2.mkdir()
@@ -94,6 +97,21 @@ def test_driver_adaptive_mode(gpu_device, tmp_path):
     assert r.returncode == 0, r.stderr
     u2, meta2 = load_like_the_plot_script(out2, "FHNmodel_torus", "u")
     assert meta2["nprocs"] == 2 and rel_err(u2, want[..., 0]) <= 1e-9
+
+    # the RK4(3) pair of rounds 1-2 stays available
+    out3 = tmp_path / "rk43"
+    out3.mkdir()
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--adaptive-rk43", INI], cwd=out3, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "integrator = adaptive RK4(3) on GPU" in r.stdout
+    y, frames, h, dense = y0, [y0], 0.8 * crd.stable_dt(p), {}
+    for k, tout in enumerate(touts):
+        y, st = co.integrate_adaptive(op, y, k * d_tout, tout, h, h_max=crd.stable_dt(p), dense=dense)
+        h = st["h_next"]
+        frames.append(y)
+    u3, _ = load_like_the_plot_script(out3, "FHNmodel_torus", "u")
+    assert rel_err(u3, np.stack(frames)[..., 0]) <= 1e-9
 
 
 def test_driver_stops_when_any_slab_blows_up(gpu_device, tmp_path):

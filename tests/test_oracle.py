@@ -229,3 +229,64 @@ def test_adaptive_restatement_is_sane():
     assert rel_err(y, fine) <= 1e-3
     y2, st2 = co.integrate_adaptive(p, arr["y0"], 0.0, tout, h0=2.0, rtol=1e-8, atol=1e-12)
     assert st2["accepted"] > st["accepted"] and rel_err(y2, fine) < 0.05 * rel_err(y, fine) + 1e-9
+
+
+def test_arkode_table_satisfies_its_order_conditions():
+    """oracle/arkode_erk.py restates ARKode's default explicit fourth-order table (ARK_ZONNEVELD_5_3_4) from its documentation,
+    without the library to check against; what can be checked is that the numbers ARE a 5-stage pair of orders 4 and 3: row
+    sums equal the abscissae, all eight order conditions up to order 4 for b, all four up to order 3 for the embedding -- and that
+    the embedding is NOT of order 4 (else the difference would estimate nothing)."""
+    from oracle import arkode_erk as ark
+
+    t = ark.ZONNEVELD_5_3_4
+    A, b, b2, c = np.array(t["A"]), np.array(t["b"]), np.array(t["b2"]), np.array(t["c"])
+    assert np.allclose(A.sum(axis=1), c, atol=1e-15) and np.all(np.triu(A) == 0.0) and (t["q"], t["p"]) == (4, 3)
+    Ac = A @ c
+    conditions = lambda w: [w.sum() - 1, w @ c - 1 / 2, w @ c ** 2 - 1 / 3, w @ Ac - 1 / 6,  # noqa: E731
+                            w @ c ** 3 - 1 / 4, w @ (c * Ac) - 1 / 8, w @ (A @ c ** 2) - 1 / 12, w @ (A @ Ac) - 1 / 24]
+    assert np.allclose(conditions(b), 0.0, atol=1e-15)
+    assert np.allclose(conditions(b2)[:4], 0.0, atol=2e-15) and max(abs(v) for v in conditions(b2)[4:]) > 1e-2
+    assert np.array_equal(b[:4], np.array([1, 2, 2, 1]) / 6.0) and b[4] == 0.0  # the propagated solution is classical RK4
+    # the error weights the kernel uses: b - b2 = (2/3, -2, -2, -2, 16/3)
+    assert np.allclose(b - b2, [2 / 3, -2, -2, -2, 16 / 3], atol=1e-15)
+
+
+def test_arkode_restatement_behaves_like_the_documented_controller():
+    """ArkodeErk around the oracle's f(): the propagated solution of one step equals classical RK4's, the error estimate scales
+    like h^4, ARK_NORMAL output (no step is shortened; outputs inside a finished step re-interpolate without stepping; ARKode's
+    Hermite form equals the textbook one), the dead band keeps h constant for a suggested growth within [1, 1.5], a failed step
+    is followed by one of the same size, and the result converges to a fine fixed-step solution at the tolerance's scale."""
+    from oracle import arkode_erk as ark
+
+    meta, arr = load_golden("rk4_fhn_torus_outside")
+    p = oracle_problem(meta)
+    y0 = arr["y0"]
+    f = lambda t, y: co.rhs(p, t, y)  # noqa: E731
+    h = 0.02
+    ynew, err = ark.erk_attempt(f, 0.0, y0, h)
+    assert rel_err(ynew, co.rk4(p, y0, 0.0, h, 1)) <= 1e-14
+    _, err2 = ark.erk_attempt(f, 0.0, y0, h / 2)
+    assert 8.0 < np.abs(err).max() / np.abs(err2).max() < 32.0  # local error of the third-order embedding: h^4
+    tau = -0.37
+    a = [np.random.default_rng(k).standard_normal(5) for k in range(4)]
+    assert np.allclose(ark.hermite_arkode(tau, h, *a), co.hermite(1.0 + tau, h, a[0], a[1], a[2], a[3]), rtol=1e-13, atol=1e-15)
+    # controller rules
+    assert ark.pid_eta(0.1, [0.5, 1.0, 1.0], 20.0) == 1.0                      # suggested growth 1.07: inside the dead band
+    assert ark.pid_eta(0.1, [1e-6, 1.0, 1.0], 20.0) == pytest.approx(0.96 * (1e-6) ** (-0.58 / 3))  # 13.9x
+    assert ark.pid_eta(0.1, [1e-12, 1.0, 1.0], 20.0) == 20.0 and ark.pid_eta(0.1, [1e-12, 1.0, 1.0], 1e4) == pytest.approx(0.96 * (1e-10) ** (-0.58 / 3))
+    assert ark.pid_eta(0.1, [1e30, 1.0, 1.0], 1.0) == pytest.approx(0.1, rel=1e-14) and ark.pid_eta(0.1, [3.0, 1.0, 1.0], 1.0) < 1.0
+    assert ark.pid_eta(0.1, [1e-6, 1.0, 1.0], 20.0, h_max=0.12) == pytest.approx(1.2)
+    integ = ark.ArkodeErk(p, 0.0, y0)
+    y1, st1 = integ.evolve(1.0)
+    assert st1["t_internal"] >= 1.0 and abs(sum(integ.steps) - st1["t_internal"]) < 1e-12 and integ.steps[0] < 0.01 < max(integ.steps)
+    y1b, st1b = integ.evolve(st1["t_internal"])  # exactly the end of the step taken: its state, no new step
+    assert st1b["accepted"] == 0 and np.array_equal(y1b, integ.y)
+    y3, st3 = integ.evolve(3.0)
+    assert integ.netf >= 1  # this grid is diffusion-limited: error control alone finds the stability bound by failing
+    runs = [len(list(g)) for _, g in __import__("itertools").groupby(integ.steps)]
+    assert max(runs) >= 5  # the dead band: long runs of identical steps
+    fine = co.rk4(p, y0, 0.0, 3.0 / 3000, 3000)
+    assert rel_err(y3, fine) <= 2e-3
+    tight = ark.ArkodeErk(p, 0.0, y0, rtol=1e-8, atol=1e-12)
+    y3t, _ = tight.evolve(3.0)
+    assert tight.nst > integ.nst and rel_err(y3t, fine) < 0.05 * rel_err(y3, fine) + 1e-9
