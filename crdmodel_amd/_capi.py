@@ -89,7 +89,7 @@ class LaunchPlan(C.Structure):
     """crd_launch_plan"""
 
     _fields_ = [("autotune", C.c_int32), ("tuned", C.c_int32), ("one_round", C.c_int32), ("xcd_mapping", C.c_int32), ("rows", C.c_int32),
-                ("reserved", C.c_int32), ("ms_default", C.c_double), ("ms_chosen", C.c_double)]
+                ("columns_per_lane", C.c_int32), ("ms_default", C.c_double), ("ms_chosen", C.c_double)]
 
 
 class StepTiming(C.Structure):

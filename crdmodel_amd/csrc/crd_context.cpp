@@ -600,6 +600,7 @@ int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
 	out->one_round = c->plan.one_round;
 	out->xcd_mapping = c->plan.remap;
 	out->rows = c->plan.rows;
+	out->columns_per_lane = c->plan.cols;
 	out->ms_default = c->plan.ms_default;
 	out->ms_chosen = c->plan.ms_best;
 	return CRD_OK;

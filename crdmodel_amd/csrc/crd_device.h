@@ -68,6 +68,29 @@ inline Real *row0(void *plane, int nx)
 __device__ __forceinline__ double fmadd(double a, double b, double c) { return __builtin_fma(a, b, c); }
 __device__ __forceinline__ float fmadd(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 
+// Two grid columns per lane (crd_fused.hip, COLS = 2): the lane's values are a two-element vector.  In fp32 the element-wise
+// operations on it are the packed instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32: two columns per issue slot, which is
+// where gfx950's fp32 vector rate beyond its fp64 rate comes from); in fp64 they are two independent instruction streams in
+// one wavefront.  Element by element the arithmetic is the scalar sequence exactly (IEEE fma / mul / add, contraction off), so
+// one and two columns per lane give the same bits.
+typedef float float2v __attribute__((ext_vector_type(2)));
+typedef double double2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float2v fmadd(float2v a, float2v b, float2v c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ double2v fmadd(double2v a, double2v b, double2v c) { return __builtin_elementwise_fma(a, b, c); }
+
+template <typename Real, int COLS> struct LaneValue { using type = Real; };
+template <> struct LaneValue<float, 2> { using type = float2v; };
+template <> struct LaneValue<double, 2> { using type = double2v; };
+template <typename V> struct ScalarOf { using type = V; };
+template <> struct ScalarOf<float2v> { using type = float; };
+template <> struct ScalarOf<double2v> { using type = double; };
+// the constant c in every element of a V
+template <typename V>
+__device__ __forceinline__ V splat(double c)
+{
+	return (V)((typename ScalarOf<V>::type)c);
+}
+
 // 1 / x for a positive, normal x well inside the exponent range (here x >= K2^2 KR^2 KA^4 = 2.6): the hardware estimate
 // (v_rcp_f64: relative error 2^-24.4, and 3.3 times the issue cost of an fp64 FMA -- tools/rcp_probe.hip) refined by ONE Newton
 // step: relative error <= 2.2e-15 = 2^-48.7 measured over [2.6, 1e6], three orders of magnitude inside the 1e-12 parity
@@ -88,6 +111,20 @@ __device__ __forceinline__ float reciprocal(float x)
 	float r = __builtin_amdgcn_rcpf(x);
 	return fmadd(r, fmadd(-x, r, 1.0f), r);
 }
+__device__ __forceinline__ float2v reciprocal(float2v x)
+{
+	float2v r;
+	r.x = __builtin_amdgcn_rcpf(x.x);
+	r.y = __builtin_amdgcn_rcpf(x.y);
+	return fmadd(r, fmadd(-x, r, splat<float2v>(1.0)), r);
+}
+__device__ __forceinline__ double2v reciprocal(double2v x)
+{
+	double2v r;
+	r.x = reciprocal(x.x);
+	r.y = reciprocal(x.y);
+	return r;
+}
 
 // Third point-function variant besides CRD_MODEL_FHN / CRD_MODEL_GOLDBETER: Goldbeter with justDiffusion = 1, where the whole
 // reaction block, absorbing rows included, is skipped (src/GoldbeterModel_torus.cpp:668).  A compile-time variant: as a
@@ -97,37 +134,38 @@ inline int kernel_model(const SlabDesc &d) { return (d.model == CRD_MODEL_GOLDBE
 
 // rowp is the per-row parameter of the kinetics: FHN b(j) (src/FHNmodel_torus.cpp:623-632); Goldbeter v0 + v1 b(j), the
 // row-constant source term of src/GoldbeterModel_torus.cpp:715, formed once on the host (crd_create).
-template <typename Real, int MODEL>
-__device__ __forceinline__ void rhs_point(Real uC, Real uW, Real uE, Real uS, Real uN, Real v, Real cA, Real cX, Real cP, Real rowp,
-                                          Real ka4, bool zero, Real &du, Real &dv)
+// V: the lane's value type -- a Real, or two of them (two columns per lane); cX, rowp, ka4 are the same for both columns.
+template <typename V, int MODEL>
+__device__ __forceinline__ void rhs_point(V uC, V uW, V uE, V uS, V uN, V v, V cA, typename ScalarOf<V>::type cX, V cP, typename ScalarOf<V>::type rowp,
+                                          typename ScalarOf<V>::type ka4, bool zero, V &du, V &dv)
 {
 	// second differences as the reference writes them, (uE - 2 uC + uW), so that a constant field diffuses to exactly zero
-	const Real d2x = fmadd((Real)-2, uC, uE) + uW;
-	const Real d2y = fmadd((Real)-2, uC, uN) + uS;
-	const Real diff = fmadd(cA, uE - uW, fmadd(cX, d2x, cP * d2y));
+	const V d2x = fmadd(splat<V>(-2.0), uC, uE) + uW;
+	const V d2y = fmadd(splat<V>(-2.0), uC, uN) + uS;
+	const V diff = fmadd(cA, uE - uW, fmadd((V)cX, d2x, cP * d2y));
 	if (MODEL == kModelDiffusionOnly) {
 		du = diff;
-		dv = (Real)0;
+		dv = splat<V>(0.0);
 		return;
 	} else if (MODEL == CRD_MODEL_FHN) {
-		const Real u3 = (uC * uC) * uC;
-		du = diff + (fmadd((Real)3.0, uC, -u3) - v);
-		dv = (Real)kFhnEpsilon * (uC + rowp);
+		const V u3 = (uC * uC) * uC;
+		du = diff + (fmadd(splat<V>(3.0), uC, -u3) - v);
+		dv = splat<V>(kFhnEpsilon) * (uC + (V)rowp);
 	} else {
 		// v2 = VM2 z^2 / (K2^2 + z^2), v3 = VM3 y^2 z^4 / ((KR^2 + y^2)(KA^4 + z^4)) enter both equations only through
 		// w = v2 - v3 (src/GoldbeterModel_torus.cpp:715-716: dZ = v0 + v1 b - w + kf Y - k Z, dY = w - kf Y): one quotient
 		// w = (VM2 z^2 dB - VM3 y^2 z^4 dA) / (dA dB) with dA = K2^2 + z^2, dB = (KR^2 + y^2)(KA^4 + z^4) -- 23 instructions for
 		// the kinetics against 27 with the two Hill terms formed separately (this kernel is bound by fp64 issue).
-		const Real z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
-		const Real dA = (Real)(kGbK2 * kGbK2) + z2, dB = ((Real)(kGbKr * kGbKr) + y2) * (ka4 + z4);
-		const Real n2 = ((Real)kGbVm2 * z2) * dB, n3 = (((Real)kGbVm3 * y2) * z4) * dA;
-		const Real w = (n2 - n3) * reciprocal(dA * dB);
-		dv = w - (Real)kGbKf * v;
-		du = diff + fmadd(-(Real)kGbK, uC, rowp - dv);  // rowp = v0 + v1 b
+		const V z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
+		const V dA = splat<V>(kGbK2 * kGbK2) + z2, dB = (splat<V>(kGbKr * kGbKr) + y2) * ((V)ka4 + z4);
+		const V n2 = (splat<V>(kGbVm2) * z2) * dB, n3 = ((splat<V>(kGbVm3) * y2) * z4) * dA;
+		const V w = (n2 - n3) * reciprocal(dA * dB);
+		dv = w - splat<V>(kGbKf) * v;
+		du = diff + fmadd(-splat<V>(kGbK), uC, (V)rowp - dv);  // rowp = v0 + v1 b
 	}
 	if (zero) {
-		du = (Real)0;
-		dv = (Real)0;
+		du = splat<V>(0.0);
+		dv = splat<V>(0.0);
 	}
 }
 

@@ -51,41 +51,52 @@ constexpr int kMaxWavesPerBlock = 4;  // (8 strips per workgroup never measured 
 
 // Value held by lane-1 / lane+1 of this wavefront (the edge lane gets 0: it is apron garbage by design).  `old` = 0 with
 // bound_ctrl lets the DPP move write its destination without a tied input, i.e. without a copy in front of it.
-template <typename Real>
-__device__ __forceinline__ Real from_lane_below(Real x);
-template <typename Real>
-__device__ __forceinline__ Real from_lane_above(Real x);
-
-template <>
-__device__ __forceinline__ double from_lane_below<double>(double x)
+__device__ __forceinline__ double from_lane_below(double x)
 {
-
 	int lo = __double2loint(x), hi = __double2hiint(x);
 	lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
 	hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
 	return __hiloint2double(hi, lo);
 }
-template <>
-__device__ __forceinline__ double from_lane_above<double>(double x)
+__device__ __forceinline__ double from_lane_above(double x)
 {
-
 	int lo = __double2loint(x), hi = __double2hiint(x);
 	lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
 	hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
 	return __hiloint2double(hi, lo);
 }
-template <>
-__device__ __forceinline__ float from_lane_below<float>(float x)
+__device__ __forceinline__ float from_lane_below(float x)
 {
 	const int v = __float_as_int(x);
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true));
 }
-template <>
-__device__ __forceinline__ float from_lane_above<float>(float x)
+__device__ __forceinline__ float from_lane_above(float x)
 {
 	const int v = __float_as_int(x);
 	return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true));
 }
+// Two columns per lane, (x, y) = columns (2 lane, 2 lane + 1): the western neighbours of the pair are (lane-1's y, own x), the
+// eastern ones (own y, lane+1's x) -- one DPP move per direction for two columns instead of one per column.
+template <typename V2>
+__device__ __forceinline__ V2 pair_from_below(V2 v)
+{
+	V2 r;
+	r.x = from_lane_below(v.y);
+	r.y = v.x;
+	return r;
+}
+template <typename V2>
+__device__ __forceinline__ V2 pair_from_above(V2 v)
+{
+	V2 r;
+	r.x = v.y;
+	r.y = from_lane_above(v.x);
+	return r;
+}
+__device__ __forceinline__ float2v from_lane_below(float2v v) { return pair_from_below(v); }
+__device__ __forceinline__ float2v from_lane_above(float2v v) { return pair_from_above(v); }
+__device__ __forceinline__ double2v from_lane_below(double2v v) { return pair_from_below(v); }
+__device__ __forceinline__ double2v from_lane_above(double2v v) { return pair_from_above(v); }
 
 // f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a compile-time unrolled loop.
 template <typename F, int... Is>
@@ -103,6 +114,23 @@ __device__ __forceinline__ T *at_lane(T *row, unsigned byte_offset)
 	// base, which would cost a 64-bit vector add per access to put the row offset back in)
 	asm volatile("" : "+v"(byte_offset));
 	return reinterpret_cast<T *>(reinterpret_cast<Bytes *>(row) + byte_offset);
+}
+
+// ... the same address as a pointer to the lane's value (one Real, or two adjacent ones: an 8- or 16-byte access)
+template <typename V, typename T>
+__device__ __forceinline__ auto at_lane_as(T *row, unsigned byte_offset)
+{
+	using P = std::conditional_t<std::is_const<T>::value, const V, V>;
+	return reinterpret_cast<P *>(at_lane(row, byte_offset));
+}
+
+// a lane's value(s) added up in double
+__device__ __forceinline__ double lane_total(double x) { return x; }
+__device__ __forceinline__ double lane_total(float x) { return (double)x; }
+template <typename V2>
+__device__ __forceinline__ double lane_total(V2 v)
+{
+	return (double)v.x + (double)v.y;
 }
 
 // A value known to be identical in every lane, moved to scalar registers.
@@ -153,12 +181,19 @@ struct FusedArgs {
 //                e4 = 4/3 d1 - 4 d2 - 2 d3 - 2 dt k4        (err = e4 + 16/3 dt k5 one iteration later);
 //              the subtractions are exact (y_i is within a factor 2 of y wherever it matters), so what this costs against running
 //              sums is a rounding of y_i itself, 1e-16 |y| in quantities that are compared with rtol |y| + atol.
-template <typename Real, int MODEL, bool ABSORB, int EMBED>
+// COLS = 2: two adjacent grid columns per lane -- a wavefront's strip is 128 columns, 120 valid (the apron is two whole lanes a
+// side), rows are read and written with one 8-byte (fp32) or 16-byte (fp64) access per lane, a stage needs ONE DPP move per
+// direction for two columns, and the fp32 arithmetic is the packed instructions (v_pk_fma_f32 ...).  Needs an even nx (the
+// pair must not straddle the periodic seam); results are the one-column kernel's bit for bit.
+template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS>
 __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
+	static_assert(COLS == 1 || (COLS == 2 && EMBED == 0), "the embedded pairs run one column per lane");
+	using V = typename LaneValue<Real, COLS>::type;
 	constexpr bool ZONN = EMBED == 2;
 	constexpr int APRON = EMBED != 0 ? kApron + 1 : kApron;
-	constexpr int VALID = kLanes - 2 * APRON;
+	static_assert(APRON % COLS == 0, "the apron is whole lanes");
+	constexpr int VALID = COLS * kLanes - 2 * APRON;
 	// Register slots per pipeline array = unroll factor: the rows alive at once (4, or 6 with the fifth stage) -- even, because
 	// the two-deep arrays below are addressed with the slot's parity.
 	constexpr int M = EMBED != 0 ? CRD_EMBED_SLOTS : 4;
@@ -192,14 +227,14 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	const int item = chunk * a.nstrips + strip;
 	const int nx = s.nx;
 
-	int x = strip * VALID - APRON + lane;  // this lane's column, wrapped periodically (nx may be smaller than 64)
+	int x = strip * VALID - APRON + COLS * lane;  // this lane's (first) column, wrapped periodically (nx may be smaller than a strip)
 	x %= nx;
 	if (x < 0) x += nx;
 	// lane offsets in bytes, unsigned 32-bit: with a scalar row base the accesses take the `global_load v, v_off, s[base]` form and
 	// no 64-bit vector add is spent per access
-	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real), ob = (unsigned)(strip * VALID + (lane - APRON)) * (unsigned)sizeof(Real);
-	const int out_col = strip * VALID + (lane - APRON);
-	const bool lane_stores = lane >= APRON && lane < kLanes - APRON && out_col < nx;
+	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real), ob = (unsigned)(strip * VALID + (COLS * lane - APRON)) * (unsigned)sizeof(Real);
+	const int out_col = strip * VALID + (COLS * lane - APRON);
+	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;  // (two columns: nx is even, so is out_col)
 
 	const bool second = chunk >= a.nchunks1;
 	const int range_end = second ? a.row_end2 : a.row_end;
@@ -209,7 +244,9 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	const int niter = (j1 - j0) + 2 * APRON;
 	const int jlast = j1 + APRON - 1;  // last row the pipeline consumes
 
-	const Real cA = s.cA[x], cP = s.cP[x], cX = s.cX, ka4 = s.ka4;
+	const V cA = *reinterpret_cast<const V *>(s.cA + x), cP = *reinterpret_cast<const V *>(s.cP + x);
+	const Real cX = s.cX, ka4 = s.ka4;
+	const V h1 = (V)a.h1, h2 = (V)a.h2, h3 = (V)a.h3, h6 = (V)a.h6;
 	// b(j) is read-only for the whole launch and its index is uniform: through the constant address space the reads become
 	// scalar-cache loads into SGPRs (s_load_dwordx2), no vector registers and no vector-memory instruction
 	const __attribute__((address_space(4))) Real *const brow = (const __attribute__((address_space(4))) Real *)(s.brow);
@@ -235,33 +272,35 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	// loop unrolled M times every access has a compile-time slot and no value is ever moved between registers.
 	// (Zonneveld variant: the local field's stage values stay until the row's stage 4 has used them -- y1 four rows, y2 three)
 	constexpr int NV1 = ZONN ? M : 2, NV2 = ZONN ? 3 : 2;
-	Real u0[M], v0[M], U1[M], U2[M], U3[M], V1[NV1], V2[NV2], V3[2], aU[M], aV[M];
+	V u0[M], v0[M], U1[M], U2[M], U3[M], V1[NV1], V2[NV2], V3[2], aU[M], aV[M];
 	// (Keeping aU / aV in LDS instead -- 90 VGPRs, five wavefronts per SIMD -- measured 3-5 % SLOWER on every grid: the twelve LDS
 	// accesses per iteration cost more than the fifth wavefront brings.)
 #define ACC_U(S) aU[S]
 #define ACC_V(S) aV[S]
-	Real U4[M], V4[2], K4U[2], K4V[2];  // EMBED 1: y_new window and k4 of the last two rows; EMBED 2: z5 window (three rows deep) and e4
-	Real err2 = (Real)0;
+	V U4[M], V4[2], K4U[2], K4V[2];  // EMBED 1: y_new window and k4 of the last two rows; EMBED 2: z5 window (three rows deep) and e4
+	const V zero_v = splat<V>(0.0);
+	V err2 = zero_v;
 #pragma unroll
-	for (int k = 0; k < M; k++) u0[k] = v0[k] = U1[k] = U2[k] = U3[k] = aU[k] = aV[k] = U4[k] = (Real)0;
+	for (int k = 0; k < M; k++) u0[k] = v0[k] = U1[k] = U2[k] = U3[k] = aU[k] = aV[k] = U4[k] = zero_v;
 #pragma unroll
-	for (int k = 0; k < NV1; k++) V1[k] = (Real)0;
+	for (int k = 0; k < NV1; k++) V1[k] = zero_v;
 #pragma unroll
-	for (int k = 0; k < NV2; k++) V2[k] = (Real)0;
-	V3[0] = V3[1] = V4[0] = V4[1] = K4U[0] = K4U[1] = K4V[0] = K4V[1] = (Real)0;
+	for (int k = 0; k < NV2; k++) V2[k] = zero_v;
+	V3[0] = V3[1] = V4[0] = V4[1] = K4U[0] = K4U[1] = K4V[0] = K4V[1] = zero_v;
 
 	// Rows are fetched kPrefetch iterations before they enter the pipeline: with ~16 wavefronts per CU one row in flight
 	// per wavefront is far too little to cover HBM latency (Little's law), four rows (8 loads, 4 KiB per wavefront) is enough.
 	// The per-row reaction parameter b(j) rides along: a plain `s.brow[c]` at the point of use is a VECTOR load whose
 	// full latency the stage then waits for (four exposed L2 round trips per iteration, 60 % of the wave's lifetime when
 	// measured); fetched with the row and moved to scalar registers on arrival it costs nothing.
-	Real pu[kPrefetch], pv[kPrefetch], pb[kPrefetch], bq[M];
+	V pu[kPrefetch], pv[kPrefetch];
+	Real pb[kPrefetch], bq[M];
 #pragma unroll
 	for (int k = 0; k < kPrefetch; k++) {
 		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
 		const ptrdiff_t rb = row_base(jr);
-		pu[k] = CRD_ROW_LOAD(at_lane(a.in_u + rb, xb));
-		pv[k] = CRD_ROW_LOAD(at_lane(a.in_v + rb, xb));
+		pu[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
+		pv[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
 		pb[k] = brow[jr];
 	}
 #pragma unroll
@@ -292,74 +331,74 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		bq[S0] = uniform(pb[P]);
 		{
 			const ptrdiff_t rb = row_base(jn);
-			pu[P] = CRD_ROW_LOAD(at_lane(a.in_u + rb, xb));
-			pv[P] = CRD_ROW_LOAD(at_lane(a.in_v + rb, xb));
+			pu[P] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
+			pv[P] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
 			pb[P] = brow[jn];
 			jn = (jn < jlast) ? jn + 1 : jlast;
 		}
-		Real du, dv;
+		V du, dv;
 		// ---- stage 1, centre row p-1: y0 rows p-2, p-1, p -----------------------------------------------------
 		if (!GUARDED || m >= 2) {
 			const int c = p - 1;
-			rhs_point<Real, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
+			rhs_point<V, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
 			                       ABSORB && a.absorb[0] && boundary_row(c), du, dv);
-			U1[S1] = fmadd(a.h2, du, u0[S1]);
-			V1[A1] = fmadd(a.h2, dv, v0[S1]);
+			U1[S1] = fmadd(h2, du, u0[S1]);
+			V1[A1] = fmadd(h2, dv, v0[S1]);
 			if (!ZONN) {
-				ACC_U(S1) = fmadd(a.h6, du, u0[S1]);
-				ACC_V(S1) = fmadd(a.h6, dv, v0[S1]);
+				ACC_U(S1) = fmadd(h6, du, u0[S1]);
+				ACC_V(S1) = fmadd(h6, dv, v0[S1]);
 			}
 		}
 		// ---- stage 2, centre row p-2: y1 rows p-3, p-2, p-1 ---------------------------------------------------
 		if (!GUARDED || m >= 4) {
 			const int c = p - 2;
-			rhs_point<Real, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[A2], cA, cX, cP, bq[S2], ka4,
+			rhs_point<V, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[A2], cA, cX, cP, bq[S2], ka4,
 			                       ABSORB && a.absorb[1] && boundary_row(c), du, dv);
-			U2[S2] = fmadd(a.h2, du, u0[S2]);
-			V2[B2] = fmadd(a.h2, dv, v0[S2]);
+			U2[S2] = fmadd(h2, du, u0[S2]);
+			V2[B2] = fmadd(h2, dv, v0[S2]);
 			if (!ZONN) {
-				ACC_U(S2) = fmadd(a.h3, du, ACC_U(S2));
-				ACC_V(S2) = fmadd(a.h3, dv, ACC_V(S2));
+				ACC_U(S2) = fmadd(h3, du, ACC_U(S2));
+				ACC_V(S2) = fmadd(h3, dv, ACC_V(S2));
 			}
 		}
 		// ---- stage 3, centre row p-3: y2 rows p-4, p-3, p-2 ---------------------------------------------------
 		if (!GUARDED || m >= 6) {
 			const int c = p - 3;
-			rhs_point<Real, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[B3], cA, cX, cP, bq[S3], ka4,
+			rhs_point<V, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[B3], cA, cX, cP, bq[S3], ka4,
 			                       ABSORB && a.absorb[2] && boundary_row(c), du, dv);
-			U3[S3] = fmadd(a.h1, du, u0[S3]);
-			V3[S3 & 1] = fmadd(a.h1, dv, v0[S3]);
+			U3[S3] = fmadd(h1, du, u0[S3]);
+			V3[S3 & 1] = fmadd(h1, dv, v0[S3]);
 			if (!ZONN) {
-				ACC_U(S3) = fmadd(a.h3, du, ACC_U(S3));
-				ACC_V(S3) = fmadd(a.h3, dv, ACC_V(S3));
+				ACC_U(S3) = fmadd(h3, du, ACC_U(S3));
+				ACC_V(S3) = fmadd(h3, dv, ACC_V(S3));
 			}
 		}
 		// ---- stage 4, centre row p-4: y3 rows p-5, p-4, p-3 -> the new state ----------------------------------
 		if (!GUARDED || m >= 8) {
 			const int c = p - 4;
-			rhs_point<Real, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
+			rhs_point<V, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
 			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);
-			Real nu, nv;
+			V nu, nv;
 			if (ZONN) {
 				// everything the row still needs, from its stage values (see the kernel's header comment)
-				const Real yu = u0[S4], yv = v0[S4];
-				const Real d1u = U1[S4] - yu, d2u = U2[S4] - yu, d3u = U3[S4] - yu, d1v = V1[A4] - yv, d2v = V2[B4] - yv, d3v = V3[S4 & 1] - yv;
-				nu = fmadd((Real)(1.0 / 3.0), fmadd((Real)2, d2u, d1u + d3u), fmadd(a.h6, du, yu));
-				nv = fmadd((Real)(1.0 / 3.0), fmadd((Real)2, d2v, d1v + d3v), fmadd(a.h6, dv, yv));
-				const Real h32 = (Real)(-1.0 / 32.0) * a.h1, h2m = (Real)-2 * a.h1;
-				U4[Z4] = fmadd((Real)(5.0 / 16.0), d1u, fmadd((Real)(7.0 / 16.0), d2u, fmadd((Real)(13.0 / 32.0), d3u, fmadd(h32, du, yu))));
-				V4[S4 & 1] = fmadd((Real)(5.0 / 16.0), d1v, fmadd((Real)(7.0 / 16.0), d2v, fmadd((Real)(13.0 / 32.0), d3v, fmadd(h32, dv, yv))));
-				K4U[S4 & 1] = fmadd((Real)(4.0 / 3.0), d1u, fmadd((Real)-4, d2u, fmadd((Real)-2, d3u, h2m * du)));
-				K4V[S4 & 1] = fmadd((Real)(4.0 / 3.0), d1v, fmadd((Real)-4, d2v, fmadd((Real)-2, d3v, h2m * dv)));
+				const V yu = u0[S4], yv = v0[S4];
+				const V d1u = U1[S4] - yu, d2u = U2[S4] - yu, d3u = U3[S4] - yu, d1v = V1[A4] - yv, d2v = V2[B4] - yv, d3v = V3[S4 & 1] - yv;
+				nu = fmadd(splat<V>(1.0 / 3.0), fmadd(splat<V>(2.0), d2u, d1u + d3u), fmadd(h6, du, yu));
+				nv = fmadd(splat<V>(1.0 / 3.0), fmadd(splat<V>(2.0), d2v, d1v + d3v), fmadd(h6, dv, yv));
+				const V h32 = splat<V>(-1.0 / 32.0) * h1, h2m = splat<V>(-2.0) * h1;
+				U4[Z4] = fmadd(splat<V>(5.0 / 16.0), d1u, fmadd(splat<V>(7.0 / 16.0), d2u, fmadd(splat<V>(13.0 / 32.0), d3u, fmadd(h32, du, yu))));
+				V4[S4 & 1] = fmadd(splat<V>(5.0 / 16.0), d1v, fmadd(splat<V>(7.0 / 16.0), d2v, fmadd(splat<V>(13.0 / 32.0), d3v, fmadd(h32, dv, yv))));
+				K4U[S4 & 1] = fmadd(splat<V>(4.0 / 3.0), d1u, fmadd(splat<V>(-4.0), d2u, fmadd(splat<V>(-2.0), d3u, h2m * du)));
+				K4V[S4 & 1] = fmadd(splat<V>(4.0 / 3.0), d1v, fmadd(splat<V>(-4.0), d2v, fmadd(splat<V>(-2.0), d3v, h2m * dv)));
 			} else {
-				nu = fmadd(a.h6, du, ACC_U(S4));
-				nv = fmadd(a.h6, dv, ACC_V(S4));
+				nu = fmadd(h6, du, ACC_U(S4));
+				nv = fmadd(h6, dv, ACC_V(S4));
 			}
 			// Without the fifth stage rows j0 <= c < j1 are exactly iterations 8 .. niter-1; with it (one more apron row each side)
 			// the first and the last iteration of the range fall outside.
 			if ((EMBED == 0 || (c >= j0 && c < j1)) && lane_stores) {
-				*at_lane(out_row_u, ob) = nu;
-				*at_lane(out_row_v, ob) = nv;
+				*at_lane_as<V>(out_row_u, ob) = nu;
+				*at_lane_as<V>(out_row_v, ob) = nv;
 			}
 			if (EMBED == 1) {
 				U4[S4] = nu;
@@ -371,18 +410,19 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		// ---- stage 5 (EMBED), centre row p-5: y_new rows p-6, p-5, p-4 -> k5 and the error of row p-5 ----------
 		if (EMBED != 0 && (!GUARDED || m >= 10)) {
 			const int c = p - 5;
-			rhs_point<Real, MODEL>(U4[Z5], from_lane_below(U4[Z5]), from_lane_above(U4[Z5]), U4[Z6], U4[Z4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
+			rhs_point<V, MODEL>(U4[Z5], from_lane_below(U4[Z5]), from_lane_above(U4[Z5]), U4[Z6], U4[Z4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
 			                       ABSORB && a.absorb[4] && boundary_row(c), du, dv);  // k5 at t + dt like k4 (EMBED 1) or at t + 3/4 dt (Zonneveld)
 			if (lane_stores) {  // rows j0 .. j1-1 exactly: stage 5 starts at iteration 10 (row j0) and the loop ends at row j1-1
-				const Real au = u0[S5] < (Real)0 ? -u0[S5] : u0[S5], av = v0[S5] < (Real)0 ? -v0[S5] : v0[S5];
-				Real eu, ev;
+				const V au = __builtin_elementwise_abs(u0[S5]), av = __builtin_elementwise_abs(v0[S5]);
+				const V wu = fmadd((V)a.rtol, au, (V)a.atol), wv = fmadd((V)a.rtol, av, (V)a.atol);
+				V eu, ev;
 				if (ZONN) {
-					const Real h163 = (Real)(16.0 / 3.0) * a.h1;
-					eu = fmadd(h163, du, K4U[S5 & 1]) / fmadd(a.rtol, au, a.atol);
-					ev = fmadd(h163, dv, K4V[S5 & 1]) / fmadd(a.rtol, av, a.atol);
+					const V h163 = splat<V>(16.0 / 3.0) * h1;
+					eu = fmadd(h163, du, K4U[S5 & 1]) / wu;
+					ev = fmadd(h163, dv, K4V[S5 & 1]) / wv;
 				} else {
-					eu = a.h6 * (K4U[S5 & 1] - du) / fmadd(a.rtol, au, a.atol);
-					ev = a.h6 * (K4V[S5 & 1] - dv) / fmadd(a.rtol, av, a.atol);
+					eu = h6 * (K4U[S5 & 1] - du) / wu;
+					ev = h6 * (K4V[S5 & 1] - dv) / wv;
 				}
 				err2 = fmadd(eu, eu, fmadd(ev, ev, err2));
 			}
@@ -410,7 +450,7 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	if constexpr (EMBED != 0) {
 		// wavefront sum in a fixed order (butterfly over lane distances 32 .. 1), one partial per work item: the host-side
 		// reduction adds them in item order, so the norm is reproducible run to run
-		double sum = (double)err2;
+		double sum = lane_total(err2);
 		for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
 		if (lane == 0) a.err_partials[item] = sum;
 	}
@@ -450,7 +490,7 @@ const char *tuning_knob(const char *name) { return tuning_enabled() ? std::geten
 // 58.4 us with 32-row chunks and 60.5 with 16; the edge-band launches of a multi-slab step end up with 8-row chunks).
 // `one_round` (a launch-plan choice, see FusedPlan): a launch that needs more than one round of resident blocks but would
 // fit into one with chunks of up to 96 rows gets those longer chunks -- no tail round on an almost idle chip.
-template <typename Real, int MODEL>
+template <typename Real, int MODEL, int COLS>
 int resident_wavefronts()
 {
 	static int slots = 0;  // resident wavefronts of this kernel on the current device
@@ -458,7 +498,7 @@ int resident_wavefronts()
 		int dev = 0, cus = 256, blocks_per_cu = 4;
 		hipDeviceProp_t prop;
 		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0, COLS>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
 		    blocks_per_cu < 1)
 			blocks_per_cu = 4;
 		(void)hipGetLastError();
@@ -468,10 +508,16 @@ int resident_wavefronts()
 }
 
 template <typename Real, int MODEL>
-int fused_chunk_rows(int nstrips, int rows, int chunk_mode)  // 0: 32 rows, 1: one round, 2: 64 rows
+int resident_wavefronts(int cols)
+{
+	return cols == 2 ? resident_wavefronts<Real, MODEL, 2>() : resident_wavefronts<Real, MODEL, 1>();
+}
+
+template <typename Real, int MODEL>
+int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols)  // 0: 32 rows, 1: one round, 2: 64 rows
 {
 	bool one_round = chunk_mode == 1;
-	const int slots = resident_wavefronts<Real, MODEL>();
+	const int slots = resident_wavefronts<Real, MODEL>(cols);
 	int chunk = 32;
 	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
 	if (const char *e = tuning_knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
@@ -498,10 +544,14 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode)  // 0: 32 rows, 1: o
 // grid shape AND on the device: on 8192^2 fp64 mapping 1 measured -6.3 %, -0.7 % and +1.7 % against mapping 0 on three
 // MI355X of the same pool, mapping 2 -4.4 % on a fourth; one-round chunks -10 % (4096 x 1024) to +2 % (16384 x 2048 fp32) --
 // hence measured at run time, on the device and the shape at hand.  Every candidate computes bit-identical results.
+// Third dimension (round 3): columns per lane.  Two columns per lane halve the DPP moves and the apron share of a strip (8 of 128
+// columns instead of 8 of 64) and, in fp32, use the packed arithmetic; they also halve the wavefronts in flight for the same
+// bytes.  Which wins is again a matter of the kernel (fp32 / Goldbeter are issue-bound, FHN fp64 is not) and of the device.
 struct PlanCandidate {
-	int one_round, remap;  // one_round: the chunk mode -- 0 = 32 rows, 1 = stretched to one round, 2 = 64 rows
+	int one_round, remap, cols;  // one_round: the chunk mode -- 0 = 32 rows, 1 = stretched to one round, 2 = 64 rows
 };
-constexpr PlanCandidate kPlanCandidates[] = {{0, 0}, {0, 1}, {0, 2}, {1, 0}, {1, 1}, {2, 0}, {2, 1}};
+constexpr PlanCandidate kPlanCandidates[] = {{0, 0, 1}, {0, 1, 1}, {0, 2, 1}, {1, 0, 1}, {1, 1, 1}, {2, 0, 1}, {2, 1, 1},
+                                             {0, 0, 2}, {0, 1, 2}, {0, 2, 2}, {1, 0, 2}, {1, 1, 2}, {2, 0, 2}};
 
 template <typename Real, int MODEL>
 hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, int js, int ny,
@@ -527,9 +577,12 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.ny = ny;
 	a.row_begin = row_begin;
 	a.row_end = row_end;
-	const int valid = c.embed ? kValid - 2 : kValid;  // the embedded estimator's fifth stage costs one more apron column per side
-	a.nstrips = (d.nx + valid - 1) / valid;
 	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
+	// two columns per lane need an even nx (a pair must not straddle the periodic seam; rows then are 8- / 16-byte aligned too)
+	const bool cols2_ok = !c.embed && d.nx % 2 == 0;
+	// (where nothing has been measured: the packed arithmetic for fp32, one column for fp64)
+	int cols_default = (cols2_ok && sizeof(Real) == 4) ? 2 : 1;
+	if (const char *e = tuning_knob("CRD_FUSED_COLS")) cols_default = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;  // tuning knob
 	a.row_begin2 = row_begin2;
 	a.row_end2 = row_end2;
 	// Four adjacent strips per block marching in lockstep: 0.417 ms on 8192^2 fp64 against 0.441 without the barriers and
@@ -549,8 +602,13 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const bool absorb = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3] || (c.embed && c.absorb[4]));
 	const dim3 block(kLanes * sw);
 
-	auto configure = [&](int one_round, int remap) {
-		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round);
+	int cols = cols_default;
+	auto configure = [&](int one_round, int remap, int want_cols) {
+		cols = (want_cols == 2 && cols2_ok) ? 2 : 1;
+		if (const char *e = tuning_knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;  // tuning knob
+		const int valid = cols * kLanes - 2 * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
+		a.nstrips = (d.nx + valid - 1) / valid;
+		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round, cols);
 		a.nchunks1 = (rows + a.chunk - 1) / a.chunk;
 		a.nchunks = a.nchunks1 + (rows2 + a.chunk - 1) / a.chunk;
 		a.nitems = a.nstrips * a.nchunks;
@@ -559,7 +617,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		if (const char *e = tuning_knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);  // tuning knob
 		a.xs_lanes = 1;
 		if (a.remap == 2) {
-			const int nsb = (a.nstrips + sw - 1) / sw, per_xcd = resident_wavefronts<Real, MODEL>() / sw / kNumXcd;
+			const int nsb = (a.nstrips + sw - 1) / sw, per_xcd = resident_wavefronts<Real, MODEL>(cols) / sw / kNumXcd;
 			if (rows2 > 0 || a.nchunks < 2 * kNumXcd || per_xcd < nsb) {
 				a.remap = 0;  // two row ranges, or too few chunks / slots for lanes: plain order
 			} else {
@@ -573,18 +631,21 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		if (c.embed) {
 			if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
 			if (c.embed == 2) {
-				if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 2><<<a.nblocks, block, 0, st>>>(s, a);
-				else crd_rk4_fused_step_kernel<Real, MODEL, false, 2><<<a.nblocks, block, 0, st>>>(s, a);
+				if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 2, 1><<<a.nblocks, block, 0, st>>>(s, a);
+				else crd_rk4_fused_step_kernel<Real, MODEL, false, 2, 1><<<a.nblocks, block, 0, st>>>(s, a);
 			} else if (absorb) {
-				crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 1><<<a.nblocks, block, 0, st>>>(s, a);
+				crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 1, 1><<<a.nblocks, block, 0, st>>>(s, a);
 			} else {
-				crd_rk4_fused_step_kernel<Real, MODEL, false, 1><<<a.nblocks, block, 0, st>>>(s, a);
+				crd_rk4_fused_step_kernel<Real, MODEL, false, 1, 1><<<a.nblocks, block, 0, st>>>(s, a);
 			}
 			crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
+		} else if (cols == 2) {
+			if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 0, 2><<<a.nblocks, block, 0, st>>>(s, a);
+			else crd_rk4_fused_step_kernel<Real, MODEL, false, 0, 2><<<a.nblocks, block, 0, st>>>(s, a);
 		} else if (absorb) {
-			crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 0><<<a.nblocks, block, 0, st>>>(s, a);
+			crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 0, 1><<<a.nblocks, block, 0, st>>>(s, a);
 		} else {
-			crd_rk4_fused_step_kernel<Real, MODEL, false, 0><<<a.nblocks, block, 0, st>>>(s, a);
+			crd_rk4_fused_step_kernel<Real, MODEL, false, 0, 1><<<a.nblocks, block, 0, st>>>(s, a);
 		}
 		return launch_status();
 	};
@@ -606,14 +667,15 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		int reps = 3;
 		for (int k = 0; k < kCandidates; k++) {
 			t_best[k] = 0.f;
-			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap);
-			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0)) ;  // (same as a 32-row plan)
+			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols);
+			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols));  // (same as a 32-row plan)
 			if (live[k] && kPlanCandidates[k].remap != a.remap) live[k] = false;  // (the mapping fell back to dispatch order)
+			if (live[k] && kPlanCandidates[k].cols != cols) live[k] = false;      // (two columns per lane not possible here, or pinned by a knob)
 		}
 		for (int round = 0; round < kRounds && err == hipSuccess; round++)
 			for (int k = 0; err == hipSuccess && k < kCandidates; k++) {
 				if (!live[k]) continue;
-				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap);
+				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols);
 				float ms = 0.f;
 				for (int pass = 0; pass < 2 && err == hipSuccess; pass++) {
 					err = fire();  // warm-up of this variant
@@ -628,8 +690,8 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (err != hipSuccess) break;
 				ms /= (float)reps;
 				if (std::getenv("CRD_AUTOTUNE_VERBOSE"))
-					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d: %.4f ms per launch (%d launches timed)\n", d.nx, rows,
-					             round, kPlanCandidates[k].one_round, a.chunk, a.remap, ms, reps);
+					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane: %.4f ms per launch (%d launches timed)\n",
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, ms, reps);
 				if (t_best[k] == 0.f || ms < t_best[k]) t_best[k] = ms;
 			}
 		int best_k = 0;
@@ -643,12 +705,15 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		plan->tuned = 1;
 		plan->one_round = kPlanCandidates[best_k].one_round;
 		plan->remap = kPlanCandidates[best_k].remap;
+		plan->cols = kPlanCandidates[best_k].cols;
 		plan->rows = rows;
 		plan->ms_default = base;
 		plan->ms_best = best_k ? best : base;
 	}
 	const bool use_plan = plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows;
-	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0);
+	// (launches the plan was not measured on -- edge bands, short ranges -- still take its columns per lane: that choice is about
+	// the kernel's arithmetic, not about the launch's shape)
+	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default);
 	return fire();
 }
 

@@ -61,6 +61,7 @@ struct FusedPlan {
 	int autotune = 1;
 	int tuned = 0;
 	int one_round = 0, remap = 0;
+	int cols = 1;                          // grid columns per lane (1 or 2)
 	int rows = 0;                          // height of the launch the plan was measured on
 	float ms_default = 0.f, ms_best = 0.f;  // measured launch times of the plain plan and of the chosen one
 };

@@ -386,7 +386,8 @@ typedef struct crd_launch_plan {
 	int32_t one_round;    /* chunk mode: 0 = 32-row chunks, 1 = stretched so that all workgroups are resident at once, 2 = 64-row chunks */
 	int32_t xcd_mapping;  /* 0 theta-first dispatch order, 1 one contiguous band of the slab per XCD, 2 the same with succession in phi */
 	int32_t rows;         /* height of the launch it was measured on */
-	int32_t reserved;
+	int32_t columns_per_lane; /* 1: a wavefront steps a strip of 64 columns (56 valid); 2: 128 columns (120 valid), two per lane -- packed
+	                           * arithmetic in fp32 */
 	double ms_default, ms_chosen; /* measured launch times: plain plan, chosen plan */
 } crd_launch_plan;
 int crd_set_autotune(crd_ctx *ctx, int on);
