@@ -214,6 +214,9 @@ void crd_destroy(crd_ctx *c)
 		if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->ev_diag) (void)hipEventDestroy(e);
+	if (c->flag_dev) (void)hipFree(c->flag_dev);
+	if (c->halo_flag_dev) (void)hipFree(c->halo_flag_dev);
+	if (c->flag_counter) (void)hipFree(c->flag_counter);
 	if (c->ev_agree) (void)hipEventDestroy(c->ev_agree);
 	if (c->agree_dev) (void)hipFree(c->agree_dev);
 	if (c->agree_host) (void)hipHostFree(c->agree_host);

@@ -152,6 +152,20 @@ struct crd_ctx {
 	int cycle_pos = -1;
 	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
 	int cycle_start = -1;  // the decision for the call in progress, taken for ALL slabs of the run before any thread issues (run_steps)
+	// Flag-triggered exchange (RCCL runs, one-launch stepper): the last step of an exchange cycle is ONE launch whose first blocks
+	// are the edge bands; when those are in memory the kernel writes flag_epoch to *flag_dev (signal memory) and the halo
+	// exchange, parked on the comm stream with hipStreamWaitValue64, goes ahead under the rest of the launch.  flag_mode: -1 not
+	// tried yet, 0 unavailable / switched off (CRD_FLAG_EXCHANGE=0): separate band launch + event, as in rounds 1-2; bit 0: this.
+	// Bit 1 of flag_mode: the same primitive the other way round -- the comm stream writes halo_epoch to *halo_flag_dev behind
+	// the exchange (hipStreamWriteValue64) and the compute stream waits for that value instead of for an event.
+	int flag_mode = -1;
+	unsigned long long *halo_flag_dev = nullptr;
+	unsigned long long halo_epoch = 0;
+	unsigned long long *flag_dev = nullptr;
+	unsigned *flag_counter = nullptr;
+	unsigned long long flag_epoch = 0;
+	bool flag_pending = false;  // the exchange about to be issued waits for the flag, not for ev_edges
+
 	// RCCL runs: the ranks AGREE on the cycle position at the start of every stepping call (one 2-value ncclAllReduce(min) of
 	// (pos, -pos) on the comm stream, overlapped with the call's first step where that step involves no exchange): a rank whose
 	// state is new -- an upload on that rank only, a failed call -- makes every rank start afresh with an exchange instead of

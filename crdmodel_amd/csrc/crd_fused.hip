@@ -150,14 +150,21 @@ struct FusedArgs {
 	Real h2, h3, h6, h1;      // dt/2, dt/3, dt/6, dt
 	int absorb[5];            // t_stage < tBoundary for the four stages (+ the embedded pair's fifth)
 	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
-	int row_begin, row_end;   // rows of the slab this launch produces ...
-	int row_begin2, row_end2; // ... plus an optional second range (the two edge bands of a slab go in one launch)
-	int nchunks1;             // chunks of the first range
-	int chunk;                // rows per work item
+	// Rows this launch produces: up to three ranges, each cut into work items ("chunks") of its own length; chunk ids run through
+	// the ranges in order (range k holds ids [first[k], first[k+1])).  One range: an ordinary sweep.  Two: the rows of a step that
+	// read ghost rows, below and above the slab.  Three: the last step of an exchange cycle as ONE launch -- the two edge bands
+	// first (short chunks, lowest block ids: dispatched first) and the interior behind them.
+	int r_begin[3], r_end[3], r_chunk[3], r_first[3];
 	int nstrips, nitems, nblocks, remap;
 	int xs_lanes;             // remap 2: phi-lanes of chunk sequences per strip block and XCD
-	int nchunks;              // chunks of both ranges
+	int nchunks;              // chunks of all ranges
 	int sw;                   // wavefronts per block = adjacent strips a block covers
+	// Flag-triggered exchange: blocks of the chunks [0, flag_chunks) -- the edge bands -- count themselves in when their rows are
+	// in memory; the last one writes flag_value to `flag` (signal memory), which releases the halo exchange waiting on the
+	// second stream (hipStreamWaitValue64) while the interior blocks of this same launch are still running.
+	int flag_chunks, flag_blocks;
+	unsigned *flag_counter;
+	unsigned long long *flag, flag_value;
 	double *err_partials;     // EMBED: one weighted square sum per work item
 	Real rtol, atol;          // EMBED: error weights 1 / (rtol |y_n| + atol)
 };
@@ -207,19 +214,30 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	// A block's wavefronts take adjacent strips of ONE chunk, blocks walk theta first.  The wavefronts of a block therefore
 	// run the same trip counts, and in lockstep (one barrier per pipeline iteration) their row reads reach the memory system
 	// together as one contiguous, overlapping run of a.sw x 448 B per row instead of drifting apart.
-	const int blk = a.remap == 1 ? xcd_remap((int)blockIdx.x, a.nblocks) : (int)blockIdx.x;
 	const int nsb = (a.nstrips + a.sw - 1) / a.sw;
-	int sblk = blk % nsb, cblk = blk / nsb;
-	if (a.remap == 2) {
-		// Succession in phi: XCD x owns a contiguous run of chunks; its resident workgroups form `xs_lanes` lanes per strip
-		// block, and the workgroup that takes a finished one's place (ids are dispatched in order, 8 apart on one XCD) continues
-		// that lane with the NEXT chunk in phi -- whose first rows are the rows its predecessor has just read into this L2.
-		const int x = blk % kNumXcd, p = blk / kNumXcd, width = nsb * a.xs_lanes;
-		const int d = p / width, sl = p - d * width;
-		const int c0 = (int)((long)a.nchunks * x / kNumXcd), c1 = (int)((long)a.nchunks * (x + 1) / kNumXcd);
-		const int depth = (c1 - c0 + a.xs_lanes - 1) / a.xs_lanes, lane_id = sl / nsb;
-		sblk = sl - lane_id * nsb;
-		cblk = (d < depth && c0 + lane_id * depth + d < c1) ? c0 + lane_id * depth + d : a.nchunks;  // a.nchunks: nothing to do
+	// (the edge-band blocks of a merged launch keep their dispatch order; the mapping applies to the blocks behind them)
+	const int band_blocks = a.flag_blocks, mapped_blocks = a.nblocks - band_blocks, mapped_chunks = a.nchunks - a.flag_chunks;
+	int sblk, cblk;
+	if ((int)blockIdx.x < band_blocks) {
+		sblk = (int)blockIdx.x % nsb;
+		cblk = (int)blockIdx.x / nsb;
+	} else {
+		const int b0 = (int)blockIdx.x - band_blocks;
+		const int blk = a.remap == 1 ? xcd_remap(b0, mapped_blocks) : b0;
+		sblk = blk % nsb;
+		cblk = blk / nsb;
+		if (a.remap == 2) {
+			// Succession in phi: XCD x owns a contiguous run of chunks; its resident workgroups form `xs_lanes` lanes per strip
+			// block, and the workgroup that takes a finished one's place (ids are dispatched in order, 8 apart on one XCD) continues
+			// that lane with the NEXT chunk in phi -- whose first rows are the rows its predecessor has just read into this L2.
+			const int x = blk % kNumXcd, p = blk / kNumXcd, width = nsb * a.xs_lanes;
+			const int d = p / width, sl = p - d * width;
+			const int c0 = (int)((long)mapped_chunks * x / kNumXcd), c1 = (int)((long)mapped_chunks * (x + 1) / kNumXcd);
+			const int depth = (c1 - c0 + a.xs_lanes - 1) / a.xs_lanes, lane_id = sl / nsb;
+			sblk = sl - lane_id * nsb;
+			cblk = (d < depth && c0 + lane_id * depth + d < c1) ? c0 + lane_id * depth + d : mapped_chunks;  // mapped_chunks: nothing to do
+		}
+		cblk += a.flag_chunks;
 	}
 	const int strip = __builtin_amdgcn_readfirstlane(sblk * a.sw + (int)(threadIdx.x >> 6));
 	const int chunk = __builtin_amdgcn_readfirstlane(cblk);
@@ -236,10 +254,10 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	const int out_col = strip * VALID + (COLS * lane - APRON);
 	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;  // (two columns: nx is even, so is out_col)
 
-	const bool second = chunk >= a.nchunks1;
-	const int range_end = second ? a.row_end2 : a.row_end;
-	const int j0 = second ? a.row_begin2 + (chunk - a.nchunks1) * a.chunk : a.row_begin + chunk * a.chunk;
-	const int j1 = (j0 + a.chunk < range_end) ? j0 + a.chunk : range_end;
+	const int range = (chunk >= a.r_first[2]) ? 2 : (chunk >= a.r_first[1]) ? 1 : 0;  // (unused ranges start at nchunks)
+	const int range_end = a.r_end[range], range_chunk = a.r_chunk[range];
+	const int j0 = a.r_begin[range] + (chunk - a.r_first[range]) * range_chunk;
+	const int j1 = (j0 + range_chunk < range_end) ? j0 + range_chunk : range_end;
 	const int jbase = j0 - APRON;
 	const int niter = (j1 - j0) + 2 * APRON;
 	const int jlast = j1 + APRON - 1;  // last row the pipeline consumes
@@ -447,6 +465,21 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::false_type{});
 	    },
 	    std::make_integer_sequence<int, M - 1>{});
+	if (EMBED == 0 && chunk < a.flag_chunks) {
+		// An edge-band block of a merged launch (uniform over the block: its wavefronts share the chunk).  Every wavefront's stores
+		// have reached L2; then ONE wavefront writes this XCD's L2 back -- the bands must be in memory before the exchange kernel,
+		// which may run on any XCD or read them over the fabric, is let go -- and counts the block in.
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+		__builtin_amdgcn_s_barrier();
+		if (threadIdx.x == 0) {  // (the block's first wavefront always survives the strip test above: it has the lowest strip)
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+			const unsigned arrived = __hip_atomic_fetch_add(a.flag_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+			if (arrived == (unsigned)a.flag_blocks) {
+				__hip_atomic_store(a.flag_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next cycle's launch
+				__hip_atomic_store(a.flag, a.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+			}
+		}
+	}
 	if constexpr (EMBED != 0) {
 		// wavefront sum in a fixed order (butterfly over lane distances 32 .. 1), one partial per work item: the host-side
 		// reduction adds them in item order, so the norm is reproducible run to run
@@ -575,16 +608,16 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	for (int k = 0; k < 5; k++) a.absorb[k] = c.absorb[k];
 	a.js = js;
 	a.ny = ny;
-	a.row_begin = row_begin;
-	a.row_end = row_end;
 	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
 	// two columns per lane need an even nx (a pair must not straddle the periodic seam; rows then are 8- / 16-byte aligned too)
 	const bool cols2_ok = !c.embed && d.nx % 2 == 0;
 	// (where nothing has been measured: the packed arithmetic for fp32, one column for fp64)
 	int cols_default = (cols2_ok && sizeof(Real) == 4) ? 2 : 1;
 	if (const char *e = tuning_knob("CRD_FUSED_COLS")) cols_default = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;  // tuning knob
-	a.row_begin2 = row_begin2;
-	a.row_end2 = row_end2;
+	// A merged last step of an exchange cycle: rows [0, nyl) as bands + interior (see FusedArgs)
+	const int band = c.band_rows;
+	const bool merged = band > 0;
+	if (merged && (rows2 != 0 || c.embed || rows < 4 * band || !c.flag || !c.flag_counter)) return hipErrorInvalidValue;
 	// Four adjacent strips per block marching in lockstep: 0.417 ms on 8192^2 fp64 against 0.441 without the barriers and
 	// 0.4205 with one barrier per four iterations (tools/tune_fused.py, interleaved in one process; fp32 0.219 vs 0.232,
 	// Goldbeter -- instruction-bound -- unchanged); 2 or 8 strips per block lose half of the gain, 3 / 5 / 6 more.
@@ -608,22 +641,59 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		if (const char *e = tuning_knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;  // tuning knob
 		const int valid = cols * kLanes - 2 * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
 		a.nstrips = (d.nx + valid - 1) / valid;
-		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round, cols);
-		a.nchunks1 = (rows + a.chunk - 1) / a.chunk;
-		a.nchunks = a.nchunks1 + (rows2 + a.chunk - 1) / a.chunk;
+		const int nsb = (a.nstrips + sw - 1) / sw;
+		int mapped_chunks;  // chunks the block -> item mapping applies to (all of them, or the interior of a merged launch)
+		a.flag_chunks = a.flag_blocks = 0;
+		a.flag_counter = nullptr;
+		a.flag = nullptr;
+		a.flag_value = 0;
+		if (merged) {
+			// bands: 8-row items (what the separate band launch of rounds 1-2 ended up with: short, so that they are done early);
+			// interior: the chunks an interior-only launch of this height would get
+			int cb = 8;
+			if (const char *e = tuning_knob("CRD_FUSED_BANDCHUNK")) cb = std::atoi(e) >= 1 ? std::atoi(e) : cb;  // tuning knob
+			const int nb = (band + cb - 1) / cb, inner = rows - 2 * band;
+			const int ci = fused_chunk_rows<Real, MODEL>(a.nstrips, inner, one_round, cols);
+			const int r0[3] = {row_begin, row_end - band, row_begin + band}, r1[3] = {row_begin + band, row_end, row_end - band}, rc[3] = {cb, cb, ci};
+			mapped_chunks = (inner + ci - 1) / ci;
+			const int first[3] = {0, nb, 2 * nb};
+			for (int k = 0; k < 3; k++) {
+				a.r_begin[k] = r0[k];
+				a.r_end[k] = r1[k];
+				a.r_chunk[k] = rc[k];
+				a.r_first[k] = first[k];
+			}
+			a.nchunks = 2 * nb + mapped_chunks;
+			a.flag_chunks = 2 * nb;
+			a.flag_blocks = nsb * a.flag_chunks;
+			a.flag_counter = c.flag_counter;
+			a.flag = c.flag;
+			a.flag_value = c.flag_value;
+		} else {
+			const int ch = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round, cols);
+			const int n1 = (rows + ch - 1) / ch, n2 = (rows2 + ch - 1) / ch;
+			mapped_chunks = a.nchunks = n1 + n2;
+			const int r0[3] = {row_begin, row_begin2, 0}, r1[3] = {row_end, row_end2, 0}, first[3] = {0, n2 > 0 ? n1 : a.nchunks, a.nchunks};
+			for (int k = 0; k < 3; k++) {
+				a.r_begin[k] = r0[k];
+				a.r_end[k] = r1[k];
+				a.r_chunk[k] = ch;
+				a.r_first[k] = first[k];
+			}
+		}
 		a.nitems = a.nstrips * a.nchunks;
-		a.nblocks = ((a.nstrips + sw - 1) / sw) * a.nchunks;
+		a.nblocks = nsb * a.nchunks;
 		a.remap = remap;
 		if (const char *e = tuning_knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);  // tuning knob
 		a.xs_lanes = 1;
 		if (a.remap == 2) {
-			const int nsb = (a.nstrips + sw - 1) / sw, per_xcd = resident_wavefronts<Real, MODEL>(cols) / sw / kNumXcd;
-			if (rows2 > 0 || a.nchunks < 2 * kNumXcd || per_xcd < nsb) {
+			const int per_xcd = resident_wavefronts<Real, MODEL>(cols) / sw / kNumXcd;
+			if (rows2 > 0 || mapped_chunks < 2 * kNumXcd || per_xcd < nsb) {
 				a.remap = 0;  // two row ranges, or too few chunks / slots for lanes: plain order
 			} else {
 				a.xs_lanes = per_xcd / nsb;
-				const int most = (a.nchunks + kNumXcd - 1) / kNumXcd;  // chunks of the best-served XCD
-				a.nblocks = kNumXcd * ((most + a.xs_lanes - 1) / a.xs_lanes) * nsb * a.xs_lanes;
+				const int most = (mapped_chunks + kNumXcd - 1) / kNumXcd;  // chunks of the best-served XCD
+				a.nblocks = a.flag_blocks + kNumXcd * ((most + a.xs_lanes - 1) / a.xs_lanes) * nsb * a.xs_lanes;
 			}
 		}
 	};
@@ -654,7 +724,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	// repeating it is harmless: every candidate writes the same values), then reused for every launch of similar height.
 	FusedPlan *plan = c.plan;
 	const bool plannable = plan && rows2 == 0 && (long)rows * d.nx >= (1L << 20) && !tuning_enabled();  // (under CRD_TUNING the knobs decide)
-	if (plannable && !plan->tuned && plan->autotune) {
+	if (plannable && !merged && !plan->tuned && plan->autotune) {
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		hipError_t err = hipEventCreate(&e0);
 		if (err == hipSuccess) err = hipEventCreate(&e1);
@@ -668,7 +738,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		for (int k = 0; k < kCandidates; k++) {
 			t_best[k] = 0.f;
 			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols);
-			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols));  // (same as a 32-row plan)
+			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.r_chunk[0] == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols));  // (same as a 32-row plan)
 			if (live[k] && kPlanCandidates[k].remap != a.remap) live[k] = false;  // (the mapping fell back to dispatch order)
 			if (live[k] && kPlanCandidates[k].cols != cols) live[k] = false;      // (two columns per lane not possible here, or pinned by a knob)
 		}
@@ -691,7 +761,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				ms /= (float)reps;
 				if (std::getenv("CRD_AUTOTUNE_VERBOSE"))
 					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane: %.4f ms per launch (%d launches timed)\n",
-					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, ms, reps);
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.r_chunk[0], a.remap, cols, ms, reps);
 				if (t_best[k] == 0.f || ms < t_best[k]) t_best[k] = ms;
 			}
 		int best_k = 0;

@@ -78,6 +78,13 @@ struct FusedCall {
 	int err_capacity = 0;
 	double *err_sum = nullptr;       // device: the sum, written by a follow-up reduction on the same stream
 	FusedPlan *plan = nullptr;       // launch plan of the context (nullptr: plain plan)
+	// The last step of a multi-slab exchange cycle as ONE launch (rows [0, nyl), no second range): the two edge bands of band_rows
+	// rows go first, and when they are in memory the kernel itself writes flag_value to *flag (signal memory a stream waits on
+	// with hipStreamWaitValue64); flag_counter: a zero-initialised device word the band blocks count themselves in with.
+	int band_rows = 0;
+	unsigned *flag_counter = nullptr;
+	unsigned long long *flag = nullptr;
+	unsigned long long flag_value = 0;
 };
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s);

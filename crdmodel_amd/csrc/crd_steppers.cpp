@@ -113,6 +113,33 @@ int ensure_band_stream(crd_ctx *c)
 	return CRD_OK;
 }
 
+// Signal memory + counter of the flag-triggered exchange, on first use; flag_mode = 0 when the platform has none (or
+// CRD_FLAG_EXCHANGE=0 asks for the two-launch form): the caller then takes the event path.
+int ensure_flag(crd_ctx *c)
+{
+	if (c->flag_mode >= 0) return CRD_OK;
+	c->flag_mode = 0;
+	int want = 3;  // bit 0: bands release the exchange through a flag; bit 1: the exchange releases the compute stream through one
+	if (const char *e = std::getenv("CRD_FLAG_EXCHANGE")) want = std::atoi(e) & 3;
+	if (want == 0 || c->halo != CRD_HALO_RCCL) return CRD_OK;  // (LOCAL groups pull from their neighbours' planes and wait for THEIR bands too: events)
+	void *flag = nullptr, *halo_flag = nullptr, *counter = nullptr;
+	if (hipExtMallocWithFlags(&flag, sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess ||
+	    hipExtMallocWithFlags(&halo_flag, sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess || hipMalloc(&counter, sizeof(unsigned)) != hipSuccess) {
+		(void)hipGetLastError();
+		for (void *q : {flag, halo_flag, counter})
+			if (q) (void)hipFree(q);
+		return CRD_OK;
+	}
+	HIP_TRY(c, hipMemset(flag, 0, sizeof(unsigned long long)));
+	HIP_TRY(c, hipMemset(halo_flag, 0, sizeof(unsigned long long)));
+	HIP_TRY(c, hipMemset(counter, 0, sizeof(unsigned)));
+	c->flag_dev = static_cast<unsigned long long *>(flag);
+	c->halo_flag_dev = static_cast<unsigned long long *>(halo_flag);
+	c->flag_counter = static_cast<unsigned *>(counter);
+	c->flag_mode = want;
+	return CRD_OK;
+}
+
 int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, bool timed_step)
 {
 	const int ext = kStepHalo * (kExchangeEvery - 1 - q);
@@ -140,7 +167,9 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			// (diagnostics: how long does the compute stream stand at this wait?  Zero when the exchange hid under the sweeps)
 			const bool diag = c->diag_active && 4 * c->diag_waits + 1 < (int)c->ev_diag.size();
 			if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits)], c->compute));
-			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			if (c->flag_mode > 0 && (c->flag_mode & 2) && c->halo_epoch > 0)
+				HIP_TRY(c, hipStreamWaitValue64(c->compute, c->halo_flag_dev, c->halo_epoch, hipStreamWaitValueGte, ~0ull));  // (written behind the exchange)
+			else HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
 			if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits++ + 1)], c->compute));
 			if (c->halo == CRD_HALO_LOCAL) {
 				// LOCAL halos are PULLED by the neighbours from this context's planes: the next step that overwrites those
@@ -158,8 +187,19 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
-		const FusedCall call = make_fused_call(c, t, dt, src, dst);
+		FusedCall call = make_fused_call(c, t, dt, src, dst);
 		const bool split = c->nyl >= 4 * kFusedBand;
+		if (int rc = ensure_flag(c)) return rc;
+		if (split && (c->flag_mode & 1) && !c->bands_on_own_stream && kExchangeEvery > 1) {
+			// ONE launch: edge bands as its first blocks, interior behind them; the kernel releases the exchange (flag)
+			call.band_rows = kFusedBand;
+			call.flag = c->flag_dev;
+			call.flag_counter = c->flag_counter;
+			call.flag_value = ++c->flag_epoch;
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
+			c->flag_pending = true;
+			continue;
+		}
 		if (int rc = ensure_band_stream(c)) return rc;
 		hipStream_t bs = c->bands_on_own_stream ? c->band : c->compute;
 		if (kExchangeEvery == 1) {  // per-step exchange: this step's inputs were produced by the previous split step
@@ -172,10 +212,13 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 		else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, bs));
 		HIP_TRY(c, hipEventRecord(c->ev_edges, bs));
 	}
+	bool merged[64] = {};  // (contexts whose step went out as one launch above: exchange_stage_input clears their flag_pending)
+	for (int k = 0; k < n && k < 64; k++) merged[k] = cs[k]->flag_pending;
 	if (int rc = exchange_stage_input(cs, n, dst, kGhost, true)) return rc;
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
+		if (k < 64 && merged[k]) continue;
 		if (c->nyl >= 4 * kFusedBand) {
 			const FusedCall call = make_fused_call(c, t, dt, src, dst);
 			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kFusedBand, c->nyl - kFusedBand, 0, 0, c->compute));
