@@ -165,6 +165,7 @@ struct crd_ctx {
 	unsigned *flag_counter = nullptr;
 	unsigned long long flag_epoch = 0;
 	bool flag_pending = false;  // the exchange about to be issued waits for the flag, not for ev_edges
+	bool merged_step = false;   // ... and the step it belongs to went out as one launch (no separate interior launch to follow)
 
 	// RCCL runs: the ranks AGREE on the cycle position at the start of every stepping call (one 2-value ncclAllReduce(min) of
 	// (pos, -pos) on the comm stream, overlapped with the call's first step where that step involves no exchange): a rank whose

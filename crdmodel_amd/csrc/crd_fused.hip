@@ -618,6 +618,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const int band = c.band_rows;
 	const bool merged = band > 0;
 	if (merged && (rows2 != 0 || c.embed || rows < 4 * band || !c.flag || !c.flag_counter)) return hipErrorInvalidValue;
+	// ... or a launch ALL of whose blocks count themselves in and whose last one writes the flag (band_rows = 0 with a flag: the
+	// separate edge-band launch, releasing the exchange without an event record between it and the interior launch)
+	const bool signal_all = !merged && c.flag != nullptr;
+	if (signal_all && (c.embed || !c.flag_counter)) return hipErrorInvalidValue;
 	// Four adjacent strips per block marching in lockstep: 0.417 ms on 8192^2 fp64 against 0.441 without the barriers and
 	// 0.4205 with one barrier per four iterations (tools/tune_fused.py, interleaved in one process; fp32 0.219 vs 0.232,
 	// Goldbeter -- instruction-bound -- unchanged); 2 or 8 strips per block lose half of the gain, 3 / 5 / 6 more.
@@ -680,6 +684,14 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				a.r_chunk[k] = ch;
 				a.r_first[k] = first[k];
 			}
+			if (signal_all) {
+				remap = 0;  // (every block is a "band" block: dispatch order)
+				a.flag_chunks = a.nchunks;
+				a.flag_blocks = nsb * a.nchunks;
+				a.flag_counter = c.flag_counter;
+				a.flag = c.flag;
+				a.flag_value = c.flag_value;
+			}
 		}
 		a.nitems = a.nstrips * a.nchunks;
 		a.nblocks = nsb * a.nchunks;
@@ -726,7 +738,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const bool plannable = plan && rows2 == 0 && (long)rows * d.nx >= (1L << 20) && !tuning_enabled();  // (under CRD_TUNING the knobs decide)
 	if (plannable && !merged && !plan->tuned && plan->autotune) {
 		hipEvent_t e0 = nullptr, e1 = nullptr;
-		hipError_t err = hipEventCreate(&e0);
+		// (nothing else may run on the device while candidates are timed: a halo exchange still in flight on the second stream
+		// made a ring context pick a different -- worse -- plan than a plain slab of the same shape)
+		hipError_t err = hipDeviceSynchronize();
+		if (err == hipSuccess) err = hipEventCreate(&e0);
 		if (err == hipSuccess) err = hipEventCreate(&e1);
 		// Candidates are timed round-robin, kRounds times, and each keeps its best round: a device's clock drifts while the
 		// measurement runs (a Goldbeter launch sequence lost 15 % over five candidates timed one after the other), and a

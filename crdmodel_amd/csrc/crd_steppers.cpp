@@ -119,8 +119,15 @@ int ensure_flag(crd_ctx *c)
 {
 	if (c->flag_mode >= 0) return CRD_OK;
 	c->flag_mode = 0;
-	int want = 3;  // bit 0: bands release the exchange through a flag; bit 1: the exchange releases the compute stream through one
-	if (const char *e = std::getenv("CRD_FLAG_EXCHANGE")) want = std::atoi(e) & 3;
+	// bit 0: bands + interior as ONE launch, the bands' blocks release the exchange; bit 1: the exchange releases the compute stream
+	// through a stream-written value; bit 2: the separate band launch releases the exchange itself (no event record).
+	// All three are built, bit-exact (tests) and measured on the world-size-1 ring (profiles/r03/ring_flag_variants.md) -- and
+	// all three lose against the events of rounds 1-2 on this stack: every band block's release fence is a write-back of its
+	// XCD's whole L2 (the band launch takes 24 us instead of 10 + a 7 us event bubble), the one-launch form leaves the slots of
+	// the finished band blocks to a second round of interior blocks (83 us against 10 + 7 + 50), and the value wait is a one-thread
+	// spinning kernel of 5 us where the event wait is a 6 us bubble.  Hence off unless asked for.
+	int want = 0;
+	if (const char *e = std::getenv("CRD_FLAG_EXCHANGE")) want = std::atoi(e) & 7;
 	if (want == 0 || c->halo != CRD_HALO_RCCL) return CRD_OK;  // (LOCAL groups pull from their neighbours' planes and wait for THEIR bands too: events)
 	void *flag = nullptr, *halo_flag = nullptr, *counter = nullptr;
 	if (hipExtMallocWithFlags(&flag, sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess ||
@@ -197,9 +204,10 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			call.flag_counter = c->flag_counter;
 			call.flag_value = ++c->flag_epoch;
 			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
-			c->flag_pending = true;
+			c->flag_pending = c->merged_step = true;
 			continue;
 		}
+		c->merged_step = false;
 		if (int rc = ensure_band_stream(c)) return rc;
 		hipStream_t bs = c->bands_on_own_stream ? c->band : c->compute;
 		if (kExchangeEvery == 1) {  // per-step exchange: this step's inputs were produced by the previous split step
@@ -208,12 +216,26 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 		}
 		// previous step done (its output is read, its input plane is overwritten): stream order, unless the bands have a stream of their own
 		if (c->bands_on_own_stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->ev_interior, 0));
+		// The band launch says itself when its rows are in memory (its last block writes the flag the exchange waits for): no event
+		// record between it and the interior launch, which cost the compute stream a ~6.5 us bubble per cycle.
+		const bool band_signals = split && c->flag_mode > 0 && (c->flag_mode & 4) && !c->bands_on_own_stream && kExchangeEvery > 1;
+		if (band_signals) {
+			call.flag = c->flag_dev;
+			call.flag_counter = c->flag_counter;
+			call.flag_value = ++c->flag_epoch;
+		}
 		if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, kFusedBand, c->nyl - kFusedBand, c->nyl, bs));
 		else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, bs));
-		HIP_TRY(c, hipEventRecord(c->ev_edges, bs));
+		if (band_signals) {
+			c->flag_pending = true;
+			call.flag = nullptr;
+			call.flag_counter = nullptr;
+		} else {
+			HIP_TRY(c, hipEventRecord(c->ev_edges, bs));
+		}
 	}
 	bool merged[64] = {};  // (contexts whose step went out as one launch above: exchange_stage_input clears their flag_pending)
-	for (int k = 0; k < n && k < 64; k++) merged[k] = cs[k]->flag_pending;
+	for (int k = 0; k < n && k < 64; k++) merged[k] = cs[k]->flag_pending && cs[k]->merged_step;
 	if (int rc = exchange_stage_input(cs, n, dst, kGhost, true)) return rc;
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
