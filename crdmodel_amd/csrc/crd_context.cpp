@@ -56,6 +56,22 @@ int ensure_staging(crd_ctx *c, size_t bytes)
 	return CRD_OK;
 }
 
+// One field plane.  Planes are whole multiples of 64 KiB (a row of 8192 doubles) and of 512 KiB at the BASELINE sizes, so with
+// back-to-back allocations element (j, i) of every plane a step touches -- two read, two written -- sits at the same offset
+// modulo any power-of-two interleave of the memory channels.  plane_skew (CRD_PLANE_SKEW, bytes) staggers the planes inside
+// their allocations, plane number x skew, to take that alignment away.
+int alloc_plane(crd_ctx *c, int k, int f)
+{
+	const size_t index = (size_t)(2 * k + f), skew = c->plane_skew * index;
+	void *base = nullptr;
+	hipError_t e = hipMalloc(&base, c->plane_bytes + skew);
+	if (e != hipSuccess) return fail(c, e == hipErrorOutOfMemory ? CRD_ENOMEM : CRD_EHIP, std::string("hipMalloc(plane): ") + hipGetErrorString(e));
+	c->plane_allocs.push_back(base);
+	c->plane[k][f] = static_cast<char *>(base) + skew;
+	HIP_TRY(c, hipMemsetAsync(c->plane[k][f], 0, c->plane_bytes, c->compute));
+	return CRD_OK;
+}
+
 int resolve_stepper(const crd_ctx *c)
 {
 	if (c->stepper == CRD_STEPPER_STAGED) return CRD_STEPPER_STAGED;
@@ -157,11 +173,11 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_interior, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreate(&c->ev_t0));
 	CREATE_TRY(hipEventCreate(&c->ev_t1));
+	c->plane_skew = 16640;  // 16 KiB + 256 B (profiles/r03/plane_skew.txt: -3 % at 8192^2 fp64 on one box, -5 % Goldbeter 4096^2 on another, nowhere a loss beyond run-to-run noise)
+	if (const char *e = std::getenv("CRD_PLANE_SKEW")) c->plane_skew = (size_t)std::max(0L, std::atol(e)) & ~(size_t)255;  // (rows stay 256-byte aligned)
 	for (int k = 0; k < crd_ctx::OUT; k++)  // (the OUT plane is allocated by the first dense-output call)
-		for (int f = 0; f < 2; f++) {
-			CREATE_TRY(hipMalloc(&c->plane[k][f], c->plane_bytes));
-			CREATE_TRY(hipMemsetAsync(c->plane[k][f], 0, c->plane_bytes, c->compute));
-		}
+		for (int f = 0; f < 2; f++)
+			if ((rc = alloc_plane(c, k, f))) return bail(rc);
 	CREATE_TRY(hipMalloc(&c->ghost_lo, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc(&c->ghost_hi, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc(&c->edge_lo, (size_t)c->nx * c->real_size));
@@ -206,9 +222,7 @@ void crd_destroy(crd_ctx *c)
 	if (c->comm) (void)hipStreamSynchronize(c->comm);
 	if (c->band) (void)hipStreamSynchronize(c->band);
 	if (c->nccl && g_rccl.handle) (void)g_rccl.CommDestroy(c->nccl);
-	for (auto &pl : c->plane)
-		for (void *q : pl)
-			if (q) (void)hipFree(q);
+	for (void *q : c->plane_allocs) (void)hipFree(q);
 	for (void *q : {c->cA, c->cP, c->brow, c->stage_in, c->stage_out, c->ghost_lo, c->ghost_hi, c->edge_lo, c->edge_hi, (void *)c->scalar_dev,
 	                (void *)c->err_partials})
 		if (q) (void)hipFree(q);

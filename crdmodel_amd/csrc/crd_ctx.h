@@ -109,6 +109,8 @@ struct crd_ctx {
 	// OUT exists only in contexts that have produced dense output (lazy): the third state plane of crd_integrate_adaptive.
 	enum { Y = 0, SA = 1, SB = 2, ACC = 3, OUT = 4, NPLANES = 5 };
 	void *plane[NPLANES][2] = {};
+	std::vector<void *> plane_allocs;  // what hipMalloc returned for them (a plane starts `plane_skew` x its index into its allocation)
+	size_t plane_skew = 0;             // bytes; see alloc_plane (crd_context.cpp)
 	void *cA = nullptr, *cP = nullptr, *brow = nullptr;
 	void *stage_in = nullptr, *stage_out = nullptr;  // AoS staging for the *_host entry points (lazy)
 	size_t stage_bytes = 0;
@@ -217,6 +219,7 @@ int fail(crd_ctx *c, int code, const std::string &msg);  // records msg (thread-
 int set_device(crd_ctx *c);
 int upload_table(crd_ctx *c, const std::vector<double> &src, void **dst);  // host doubles -> device precision
 int ensure_staging(crd_ctx *c, size_t bytes);                              // AoS staging of the *_host entry points
+int alloc_plane(crd_ctx *c, int k, int f);                                 // one field plane of state k, zeroed
 inline bool absorbing(const crd_ctx *c, double t_stage) { return t_stage < c->p.t_boundary; }  // strict <, src/FHNmodel_torus.cpp:643
 int resolve_stepper(const crd_ctx *c);  // CRD_STEPPER_STAGED / _FUSED, or -1 when the requested one is unavailable
 int check_group(crd_ctx *const *ctxs, int n);

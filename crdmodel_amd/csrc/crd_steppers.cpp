@@ -681,10 +681,8 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 		}
 		if (dense)
 			for (int f = 0; f < 2; f++)
-				if (!c->plane[crd_ctx::OUT][f]) {
-					HIP_TRY(c, hipMalloc(&c->plane[crd_ctx::OUT][f], c->plane_bytes));
-					HIP_TRY(c, hipMemsetAsync(c->plane[crd_ctx::OUT][f], 0, c->plane_bytes, c->compute));
-				}
+				if (!c->plane[crd_ctx::OUT][f])
+					if (int rc = alloc_plane(c, crd_ctx::OUT, f)) return rc;
 	}
 	for (int k = 0; k < n; k++) cs[k]->cycle_pos = -1;  // the integrator exchanges as it needs; a fixed-step call afterwards starts afresh
 	crd_adaptive_stats st{};
