@@ -12,6 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # CRD_LIBRARY points the binding at another build of the same ABI (tuning builds under tools/); default is the in-tree library.
 LIB_PATH = os.environ.get("CRD_LIBRARY") or os.path.join(_PKG, "libcrd.so")
 
+ABI_VERSION = 3  # CRD_ABI_VERSION of include/crd.h (tests/test_host_abi.py keeps the two in step)
 OK, EINVAL, ENOMEM, EHIP, ERCCL, EIO, EPARSE, ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
 MODEL_FHN, MODEL_GOLDBETER = 0, 1
 SURFACE_TORUS, SURFACE_FLAT = 0, 1
@@ -206,7 +207,7 @@ def lib():
             fn = getattr(L, name)  # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if L.crd_abi_version() != 3:
+        if L.crd_abi_version() != ABI_VERSION:
             raise ImportError("libcrd.so ABI version mismatch")
         _lib = L
     return _lib

@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     # and the ctypes table binds exactly the declared set, so a header change cannot go unbound
     assert sorted(crd._capi._SIGNATURES) == names
-    assert crd._capi.lib().crd_abi_version() == 3
+    header_version = int(re.search(r"#define CRD_ABI_VERSION (\d+)", open(os.path.join(ROOT, "include", "crd.h")).read()).group(1))
+    assert crd._capi.lib().crd_abi_version() == crd._capi.ABI_VERSION == header_version
 
 
 def test_status_strings():
