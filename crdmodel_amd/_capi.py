@@ -97,7 +97,8 @@ class StepTiming(C.Structure):
     """crd_step_timing"""
 
     _fields_ = [("ms_total", C.c_double), ("kernel_ms", C.c_double), ("exposed_halo_ms", C.c_double), ("exchange_ms", C.c_double),
-                ("steps", C.c_int64), ("halo_waits", C.c_int32), ("exchanges", C.c_int32), ("agreement_restarts", C.c_int64)]
+                ("steps", C.c_int64), ("halo_slack", C.c_int32), ("reserved", C.c_int32), ("halo_waits", C.c_int32), ("exchanges", C.c_int32),
+                ("agreement_restarts", C.c_int64)]
 
 
 # name -> (restype, argtypes); the test suite checks this table against include/crd.h symbol by symbol.
@@ -160,6 +161,7 @@ _SIGNATURES = {
     "crd_get_launch_plan": (C.c_int, [_vp, C.POINTER(LaunchPlan)]),
     "crd_plan_launches": (C.c_int, [_vp]),
     "crd_set_diagnostics": (C.c_int, [_vp, C.c_int]),
+    "crd_set_halo_slack": (C.c_int, [_vp, C.c_int]),
     "crd_get_step_timing": (C.c_int, [_vp, C.POINTER(StepTiming)]),
 }
 

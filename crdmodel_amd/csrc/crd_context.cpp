@@ -145,6 +145,7 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	c->plane_bytes = (size_t)(c->nyl + 2 * kGhost) * (size_t)c->nx * c->real_size;
 	c->halo = n_slabs == 1 ? CRD_HALO_SELF : -1;  // multi-slab contexts must be wired before use
 	if (const char *e = std::getenv("CRD_BAND_STREAM")) c->bands_on_own_stream = std::atoi(e) != 0;
+	if (const char *e = std::getenv("CRD_HALO_SLACK")) c->halo_slack = std::atoi(e) == 2 ? 2 : 1;
 	if (const char *e = std::getenv("CRD_AUTOTUNE")) c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = std::atoi(e) != 0;
 
 	int ndev = 0;

@@ -151,6 +151,11 @@ struct crd_ctx {
 	// Multi-slab fused stepping: position in the deep-halo exchange cycle the resident state is at (steps taken since the ghost
 	// rows were last exchanged, 0 = just exchanged), or -1 when the ghost rows cannot be trusted (new state, another stepper,
 	// an error): crd_step_rk4 then starts with an exchange, otherwise it carries on where the previous call stopped.
+	// Halo slack: sweeps of owned-only rows the compute stream launches after an exchange before it waits for the halo -- 1: the
+	// cycle's first step is split (rounds 1-2); 2: the first two are, for a third sweep of cover (crd_set_halo_slack, CRD_HALO_SLACK).
+	int halo_slack = 1;
+	bool ghost_deferred = false;  // step 0 of the cycle has launched its owned-only rows; its ghost readers wait for step 1
+	double deferred_t = 0.0;      // that step's time
 	int cycle_pos = -1;
 	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
 	int cycle_start = -1;  // the decision for the call in progress, taken for ALL slabs of the run before any thread issues (run_steps)

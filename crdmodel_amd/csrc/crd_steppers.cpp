@@ -147,7 +147,27 @@ int ensure_flag(crd_ctx *c)
 	return CRD_OK;
 }
 
-int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, bool timed_step)
+// The compute stream's wait for the halo of the exchange just made (and, in a LOCAL group, for the neighbours to have pulled
+// theirs out of this context's planes), with the diagnostics' event pair around it.
+int wait_for_halo(crd_ctx *c)
+{
+	// (diagnostics: how long does the compute stream stand at this wait?  Zero when the exchange hid under the sweeps)
+	const bool diag = c->diag_active && 4 * c->diag_waits + 1 < (int)c->ev_diag.size();
+	if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits)], c->compute));
+	if (c->flag_mode > 0 && (c->flag_mode & 2) && c->halo_epoch > 0)
+		HIP_TRY(c, hipStreamWaitValue64(c->compute, c->halo_flag_dev, c->halo_epoch, hipStreamWaitValueGte, ~0ull));  // (written behind the exchange)
+	else HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+	if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits++ + 1)], c->compute));
+	if (c->halo == CRD_HALO_LOCAL) {
+		// LOCAL halos are PULLED by the neighbours from this context's planes: the next launch that overwrites those rows must not
+		// start before both neighbours have finished copying them
+		HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + c->n_slabs - 1) % c->n_slabs)]->ev_halo, 0));
+		HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + 1) % c->n_slabs)]->ev_halo, 0));
+	}
+	return CRD_OK;
+}
+
+int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, bool timed_step, bool last_step_of_call)
 {
 	const int ext = kStepHalo * (kExchangeEvery - 1 - q);
 	if (q < kExchangeEvery - 1) {
@@ -156,6 +176,20 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			if (int rc = set_device(c)) return rc;
 			const FusedCall call = make_fused_call(c, t, dt, src, dst);
 			const bool timed = timed_step && !c->ev_k.empty();
+			if (q == 1 && c->ghost_deferred) {
+				// Halo slack 2 (crd_set_halo_slack): the exchange gets a THIRD sweep to land under.  The cycle's first step has only
+				// launched its rows that read owned rows; this step does the same -- rows [B, nyl - B) only, B = the band the
+				// exchange sends from / the neighbours pull from, which nobody may overwrite before the exchange is through -- and
+				// only then the compute stream waits, finishes step 0 (the rows that read ghost rows) and step 1 (its edges).
+				const FusedCall call0 = make_fused_call(c, c->deferred_t, dt, dst, src);  // step 0 read this step's output plane and wrote its input plane
+				const int ext0 = kStepHalo * (kExchangeEvery - 1);
+				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kFusedBand, c->nyl - kFusedBand, 0, 0, c->compute));
+				if (int rc = wait_for_halo(c)) return rc;
+				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call0, -ext0, kStepHalo, c->nyl - kStepHalo, c->nyl + ext0, c->compute));
+				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, kFusedBand, c->nyl - kFusedBand, c->nyl + ext, c->compute));
+				c->ghost_deferred = false;
+				continue;
+			}
 			if (q > 0) {
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
@@ -171,19 +205,12 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			const bool split = c->nyl >= 4 * kFusedBand;
 			if (c->bands_on_own_stream) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));  // otherwise the bands ran on this very stream
 			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kStepHalo, c->nyl - kStepHalo, 0, 0, c->compute));
-			// (diagnostics: how long does the compute stream stand at this wait?  Zero when the exchange hid under the sweeps)
-			const bool diag = c->diag_active && 4 * c->diag_waits + 1 < (int)c->ev_diag.size();
-			if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits)], c->compute));
-			if (c->flag_mode > 0 && (c->flag_mode & 2) && c->halo_epoch > 0)
-				HIP_TRY(c, hipStreamWaitValue64(c->compute, c->halo_flag_dev, c->halo_epoch, hipStreamWaitValueGte, ~0ull));  // (written behind the exchange)
-			else HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
-			if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits++ + 1)], c->compute));
-			if (c->halo == CRD_HALO_LOCAL) {
-				// LOCAL halos are PULLED by the neighbours from this context's planes: the next step that overwrites those
-				// rows (q = 1) must not start before both neighbours have finished copying them
-				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + c->n_slabs - 1) % c->n_slabs)]->ev_halo, 0));
-				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->group[(size_t)((c->slab + 1) % c->n_slabs)]->ev_halo, 0));
+			if (split && c->halo_slack >= 2 && !last_step_of_call && !c->bands_on_own_stream && kExchangeEvery > 3) {
+				c->ghost_deferred = true;  // the wait and the rows that read ghost rows follow behind the NEXT step's owned-only rows
+				c->deferred_t = t;
+				continue;
 			}
+			if (int rc = wait_for_halo(c)) return rc;
 			// the rows that read ghost rows: [-ext, kStepHalo) and [nyl - kStepHalo, nyl + ext) in one launch
 			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, kStepHalo, c->nyl - kStepHalo, c->nyl + ext, c->compute));
 			else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
@@ -369,6 +396,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		bool agreement_pending = false;
 		if (nsteps > 0) {
 			for (int k = 0; k < n; k++) cs[k]->cycle_pos = -1;  // until this call has gone through
+			for (int k = 0; k < n; k++) cs[k]->ghost_deferred = false;  // (a call always finishes what its last step deferred)
 			if (ring) {
 				if (int rc = begin_cycle_agreement(lead, q0)) return rc;
 				agreement_pending = true;
@@ -389,11 +417,11 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			// time one launch of the dominant kernel mid-run (fused: the first one-launch step of a cycle)
 			// (fused: a step of the cycle that is one full-height launch, i.e. neither the split first nor the split last one)
 			const bool timed_step = timed_launches && !timed &&
-			                        (fused ? (q >= 1 && q <= kExchangeEvery - 2 && (s >= nsteps / 2 || s + kExchangeEvery >= nsteps)) : s >= nsteps / 2);
+			                        (fused ? (q >= (lead->halo_slack >= 2 ? 2 : 1) && q <= kExchangeEvery - 2 && (s >= nsteps / 2 || s + kExchangeEvery >= nsteps)) : s >= nsteps / 2);
 			const double t = t0 + (double)s * dt;
 			if (fused) {
 				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
-				if (int rc = fused_step_multi(cs, n, t, dt, cur, dst, q, timed_step)) return rc;
+				if (int rc = fused_step_multi(cs, n, t, dt, cur, dst, q, timed_step, s + 1 == nsteps)) return rc;
 				cur = dst;
 			} else if (int rc = staged_step_multi(cs, n, t, dt, timed_step)) {
 				return rc;
@@ -407,6 +435,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 					// Some rank holds a new state: every rank starts afresh.  The step just issued wrote the scratch planes only (plane Y
 					// is untouched) and is overwritten by the one issued again below, in stream order.
 					lead->agreement_restarts++;
+					for (int k = 0; k < n; k++) cs[k]->ghost_deferred = false;  // (the step issued ahead of the answer is void, and so is what it deferred)
 					if (int rc = prime_halo(cs, n, crd_ctx::Y, kGhost, true)) return rc;
 					q0 = 0;
 					cur = crd_ctx::Y;
@@ -696,7 +725,9 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	double t_prev = t0;
 	// A call continues the previous one when it starts at the output time that one handed back and nothing has replaced the state
 	// since (ARKode keeps its memory between ARKode() calls the same way); the ARKode-style controller also needs its own memory.
-	const bool resume = dense && lead->dense.pending && t0 == lead->dense.t_out && (!arkode_method || lead->ark.live);
+	bool resume = dense && t0 == lead->dense.t_out && (!arkode_method || lead->ark.live);
+	for (int k = 0; k < n; k++)  // (every slab of a group must still hold the step: an upload to one of them alone ends the carry-over for all)
+		resume = resume && cs[k]->dense.pending && cs[k]->dense.t_out == lead->dense.t_out && cs[k]->dense.t_np1 == lead->dense.t_np1;
 	for (int k = 0; k < n; k++)
 		if (!resume) cs[k]->dense.pending = false;
 	auto hand_back = [&](double theta, double hstep) -> int {  // interpolant of step prev -> cur at t_prev + theta hstep into plane Y, planes re-labelled
@@ -964,6 +995,14 @@ int crd_plan_launches(crd_ctx *c)
 	return CRD_OK;
 }
 
+int crd_set_halo_slack(crd_ctx *c, int sweeps)
+{
+	if (!c) return CRD_EINVAL;
+	if (sweeps != 1 && sweeps != 2) return fail(c, CRD_EINVAL, "halo slack is 1 or 2 sweeps");
+	c->halo_slack = sweeps;
+	return CRD_OK;
+}
+
 int crd_set_diagnostics(crd_ctx *c, int on)
 {
 	if (!c) return CRD_EINVAL;
@@ -1023,6 +1062,7 @@ int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double 
 	tm.ms_total = ms;
 	tm.kernel_ms = timed ? sum / timed : 0.0;
 	tm.steps = nsteps;
+	tm.halo_slack = c->halo_slack;
 	tm.halo_waits = c->diag_waits;
 	tm.exchanges = c->diag_exchanges;
 	for (int k = 0; k < c->diag_waits; k++) {

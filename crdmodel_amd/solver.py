@@ -261,11 +261,15 @@ class Slab:
         """Per-exchange event pairs in the next step_rk4_timed calls (RCCL contexts): see step_timing()."""
         self._check(lib().crd_set_diagnostics(self._h, 1 if on else 0), "crd_set_diagnostics")
 
+    def set_halo_slack(self, sweeps):
+        """1 or 2 sweeps of owned-only rows between an exchange and the wait for its halo (crd_set_halo_slack)."""
+        self._check(lib().crd_set_halo_slack(self._h, sweeps), "crd_set_halo_slack")
+
     def step_timing(self):
         """What the last step_rk4_timed call measured (crd_step_timing) as a dict."""
         tm = capi.StepTiming()
         self._check(lib().crd_get_step_timing(self._h, C.byref(tm)), "crd_get_step_timing")
-        return {f: getattr(tm, f) for f, _ in tm._fields_}
+        return {f: getattr(tm, f) for f, _ in tm._fields_ if f != "reserved"}
 
     def dominant_kernel_rows(self):
         v = C.c_int64()
@@ -373,6 +377,10 @@ class LocalGroup:
     def set_stepper(self, stepper):
         for s in self.slabs:
             s.set_stepper(stepper)
+
+    def set_halo_slack(self, sweeps):
+        for s in self.slabs:
+            s.set_halo_slack(sweeps)
 
     def integrate_adaptive(self, t0, tout, **options):
         opt, st = _adaptive_options(options), capi.AdaptiveStats()

@@ -360,12 +360,19 @@ typedef struct crd_step_timing {
 	double exposed_halo_ms;     /* sum over halo_waits */
 	double exchange_ms;         /* sum over exchanges */
 	int64_t steps;
+	int32_t halo_slack;         /* crd_set_halo_slack at the time of the call */
+	int32_t reserved;
 	int32_t halo_waits;         /* waits measured (at most 64 per call) */
 	int32_t exchanges;          /* exchanges measured */
 	int64_t agreement_restarts; /* stepping calls of this context that started afresh with an exchange because the ring's ranks stood
 	                             * at different positions of the exchange cycle (see crd_step_rk4) */
 } crd_step_timing;
 int crd_set_diagnostics(crd_ctx *ctx, int on);
+/* How many sweeps of rows that read owned rows only the one-launch stepper puts between an exchange and its wait for the halo:
+ * 1 (default) splits the first step of an exchange cycle, 2 the first two -- one more small launch per cycle for a third sweep
+ * of cover, for links on which the exchange does not land within two (exposed_halo_ms says so).  A rank-local choice: it moves
+ * the point where THIS rank consumes its halo, not the exchange; results are bit-identical either way. */
+int crd_set_halo_slack(crd_ctx *ctx, int sweeps);
 int crd_get_step_timing(const crd_ctx *ctx, crd_step_timing *out);
 
 /* Rows of the slab one timed launch of the dominant kernel covers (all of them for a single slab; the interior, i.e. all
