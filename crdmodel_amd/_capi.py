@@ -109,11 +109,15 @@ _SIGNATURES = {
     "crd_config_load_ini": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(RunConfig), C.c_char_p, C.c_size_t]),
     "crd_grid_from_params": (C.c_int, [C.POINTER(Params), C.POINTER(Grid)]),
     "crd_slab_extents": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "crd_dims_create": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "crd_block_extents": (C.c_int, [C.c_int64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int] + [C.POINTER(C.c_int64)] * 4),
     "crd_steady_state": (C.c_int, [C.c_int, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "crd_steady_state_as_printed": (C.c_int, [C.c_int, C.c_double, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "crd_initial_conditions": (C.c_int, [C.POINTER(RunConfig), C.c_int64, C.c_int64, _vp]),
+    "crd_initial_conditions_block": (C.c_int, [C.POINTER(RunConfig), C.c_int64, C.c_int64, C.c_int64, C.c_int64, _vp]),
     "crd_stable_dt": (C.c_double, [C.POINTER(Params)]),
     "crd_writer_open": (C.c_int, [C.POINTER(RunConfig), C.c_char_p, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "crd_writer_open_block": (C.c_int, [C.POINTER(RunConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
     "crd_writer_write_row": (C.c_int, [_vp, _vp]),
     "crd_writer_close": (C.c_int, [_vp]),
     "crd_npy_writer_open": (C.c_int, [C.POINTER(RunConfig), C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
@@ -121,6 +125,8 @@ _SIGNATURES = {
     "crd_npy_writer_close": (C.c_int, [_vp]),
     "crd_device_count": (C.c_int, []),
     "crd_create": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "crd_create_block": (C.c_int, [C.POINTER(Params), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(_vp)]),
+    "crd_get_block": (C.c_int, [_vp] + [C.POINTER(C.c_int64)] * 4),
     "crd_destroy": (None, [_vp]),
     "crd_last_error": (C.c_char_p, [_vp]),
     "crd_get_grid": (C.c_int, [_vp, C.POINTER(Grid)]),

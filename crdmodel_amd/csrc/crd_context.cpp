@@ -75,13 +75,14 @@ int alloc_plane(crd_ctx *c, int k, int f)
 int resolve_stepper(const crd_ctx *c)
 {
 	if (c->stepper == CRD_STEPPER_STAGED) return CRD_STEPPER_STAGED;
+	if (c->d0 > 1) return c->stepper == CRD_STEPPER_FUSED ? -1 : CRD_STEPPER_STAGED;  // theta-blocks: the staged kernels only
 	// The deep-halo exchange of a multi-slab run sends kGhost owned rows: shorter slabs step with the staged kernels -- and
 	// since every slab of a run must take the same stepper, the SHORTEST slab of the run decides (each context, and each
 	// rank of an RCCL run, works that out for itself from the slab formula).
 	int64_t shortest = c->nyl;
-	for (int k = 0; c->n_slabs > 1 && k < c->n_slabs; k++) {
+	for (int k = 0; c->d1 > 1 && k < c->d1; k++) {
 		int64_t js, je;
-		if (crd_slab_extents(c->g.ny, k, c->n_slabs, &js, &je) == CRD_OK) shortest = std::min<int64_t>(shortest, je - js + 1);
+		if (crd_slab_extents(c->g.ny, k, c->d1, &js, &je) == CRD_OK) shortest = std::min<int64_t>(shortest, je - js + 1);
 	}
 	const bool can_fuse = fused_step_supported(c->p.precision, c->desc) && (c->halo == CRD_HALO_SELF || shortest >= kGhost);
 	if (c->stepper == CRD_STEPPER_FUSED) return can_fuse ? CRD_STEPPER_FUSED : -1;
@@ -118,8 +119,24 @@ const char *crd_last_error(const crd_ctx *ctx) { return ctx ? ctx->err.c_str() :
 
 int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx **out)
 {
+	return crd_create_block(p, 0, 1, slab, n_slabs, device, out);
+}
+
+int crd_get_block(const crd_ctx *c, int64_t *is, int64_t *ie, int64_t *js, int64_t *je)
+{
+	if (!c || !is || !ie || !js || !je) return CRD_EINVAL;
+	*is = c->is;
+	*ie = c->ie;
+	*js = c->js;
+	*je = c->je;
+	return CRD_OK;
+}
+
+int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int device, crd_ctx **out)
+{
 	if (!out) return CRD_EINVAL;
 	*out = nullptr;
+	const int slab = c0 * d1 + c1, n_slabs = d0 * d1;
 	std::string why;
 	if (!p || !validate_params(*p, &why)) return fail(nullptr, CRD_EINVAL, p ? why : "null params");
 	crd_ctx *c = new (std::nothrow) crd_ctx;
@@ -132,12 +149,17 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	c->p = *p;
 	int rc = crd_grid_from_params(p, &c->g);
 	if (rc) return bail(fail(c, rc, "bad geometry"));
-	rc = crd_slab_extents(c->g.ny, slab, n_slabs, &c->js, &c->je);
-	if (rc) return bail(fail(c, rc, "bad slab index / count for this ny"));
+	rc = crd_block_extents(c->g.nx, c->g.ny, c0, d0, c1, d1, &c->is, &c->ie, &c->js, &c->je);
+	if (rc) return bail(fail(c, rc, "bad block index / count for this grid"));
 	c->slab = slab;
 	c->n_slabs = n_slabs;
+	c->c0 = c0;
+	c->d0 = d0;
+	c->c1 = c1;
+	c->d1 = d1;
 	c->device = device;
-	c->nx = (int)c->g.nx;
+	c->nx = (int)(c->ie - c->is + 1);
+	if (d0 > 1 && c->nx < 2) return bail(fail(c, CRD_EINVAL, "every theta-block needs at least 2 columns"));
 	if (c->je - c->js + 1 > INT32_MAX / 2) return bail(fail(c, CRD_EINVAL, "slab too tall"));
 	c->nyl = (int)(c->je - c->js + 1);
 	if (c->nyl < 2 * kStepHalo) return bail(fail(c, CRD_EINVAL, "every slab needs at least 8 rows"));
@@ -184,6 +206,18 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	CREATE_TRY(hipMalloc(&c->edge_lo, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc(&c->edge_hi, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc((void **)&c->scalar_dev, sizeof(double)));
+	if (d0 > 1) {  // theta-blocks: ghost / edge column strips of var0, per stage-input plane and one pair for the AoS RHS
+		const size_t strip = (size_t)c->nyl * c->real_size;
+		for (int side = 0; side < 2; side++) {
+			for (int k = 0; k < crd_ctx::OUT; k++) {
+				CREATE_TRY(hipMalloc(&c->gcol[k][side], strip));
+				CREATE_TRY(hipMalloc(&c->ecol[k][side], strip));
+				CREATE_TRY(hipMemsetAsync(c->gcol[k][side], 0, strip, c->compute));
+			}
+			CREATE_TRY(hipMalloc(&c->ghost_col[side], strip));
+			CREATE_TRY(hipMalloc(&c->edge_col[side], strip));
+		}
+	}
 #undef CREATE_TRY
 
 	Coefficients co;
@@ -192,6 +226,10 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	build_beta_rows(c->p, c->g, c->js - kGhost, c->je + 1 + kGhost, &brow);
 	if (p->model == CRD_MODEL_GOLDBETER)  // the kernels take the row-constant source term v0 + v1 b(j) of src/GoldbeterModel_torus.cpp:715 ready-made
 		for (double &b : brow) b = std::fma(kGbV1, b, kGbV0);
+	if (d0 > 1) {  // the block's own columns of the per-column tables
+		co.cA = std::vector<double>(co.cA.begin() + c->is, co.cA.begin() + c->ie + 1);
+		co.cP = std::vector<double>(co.cP.begin() + c->is, co.cP.begin() + c->ie + 1);
+	}
 	if ((rc = upload_table(c, co.cA, &c->cA)) || (rc = upload_table(c, co.cP, &c->cP)) || (rc = upload_table(c, brow, &c->brow))) return bail(rc);
 
 	SlabDesc &d = c->desc;
@@ -202,7 +240,8 @@ int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx *
 	d.ka4 = std::pow(kGbKa, 4.0);  // pow(KA, p), src/GoldbeterModel_torus.cpp:695
 	d.nx = c->nx;
 	d.nyl = c->nyl;
-	d.wrap = (n_slabs == 1);
+	d.wrap = (d1 == 1);    // phi wraps inside the block
+	d.wrap_x = (d0 == 1);  // theta wraps inside the block
 	d.has_row0 = (c->js == 0);
 	d.has_rowN = (c->je == c->g.ny - 1);
 	d.js = (int)c->js;
@@ -225,8 +264,14 @@ void crd_destroy(crd_ctx *c)
 	if (c->nccl && g_rccl.handle) (void)g_rccl.CommDestroy(c->nccl);
 	for (void *q : c->plane_allocs) (void)hipFree(q);
 	for (void *q : {c->cA, c->cP, c->brow, c->stage_in, c->stage_out, c->ghost_lo, c->ghost_hi, c->edge_lo, c->edge_hi, (void *)c->scalar_dev,
-	                (void *)c->err_partials})
+	                (void *)c->err_partials, c->ghost_col[0], c->ghost_col[1], c->edge_col[0], c->edge_col[1]})
 		if (q) (void)hipFree(q);
+	for (auto &pl : c->gcol)
+		for (void *q : pl)
+			if (q) (void)hipFree(q);
+	for (auto &pl : c->ecol)
+		for (void *q : pl)
+			if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->ev_diag) (void)hipEventDestroy(e);
 	if (c->flag_dev) (void)hipFree(c->flag_dev);
@@ -273,7 +318,8 @@ int crd_comm_attach_local(crd_ctx *const *ctxs, int n)
 	if (n == 1) return CRD_OK;
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = ctxs[k];
-		if (c->p.precision != ctxs[0]->p.precision || c->nx != ctxs[0]->nx) return fail(ctxs[0], CRD_EINVAL, "contexts of one run must share nx and precision");
+		if (c->p.precision != ctxs[0]->p.precision || c->g.nx != ctxs[0]->g.nx || c->d0 != ctxs[0]->d0 || c->d1 != ctxs[0]->d1)
+			return fail(ctxs[0], CRD_EINVAL, "contexts of one run must share the grid, the decomposition and the precision");
 		c->group.assign(ctxs, ctxs + n);
 		c->halo = CRD_HALO_LOCAL;
 		// (experiment knob CRD_GROUP_OWN_STREAMS=1: every slab keeps its own streams also on a shared device, so that one slab's
@@ -318,6 +364,7 @@ int crd_comm_init_rccl(crd_ctx *c, const void *id128)
 {
 	if (!c || !id128) return CRD_EINVAL;
 	if (c->nccl) return fail(c, CRD_ESTATE, "RCCL communicator already initialised");
+	if (c->d0 > 1) return fail(c, CRD_EINVAL, "the RCCL transport moves phi-slab halos: theta-blocks (d0 > 1) run as LOCAL groups");
 	if (!g_rccl.load()) return fail(c, CRD_ERCCL, g_rccl.error);
 	if (int rc = set_device(c)) return rc;
 	ncclUniqueId id;
@@ -418,6 +465,7 @@ int crd_state_download(crd_ctx *c, void *y, int host_is_f64)
 int crd_rhs_device(crd_ctx *c, double t, const void *y, void *ydot)
 {
 	if (!c || !y || !ydot) return CRD_EINVAL;
+	if (c->d0 > 1) return fail(c, CRD_ESTATE, "theta-blocks evaluate f through crd_group_rhs_device");
 	if (c->halo < 0) return fail(c, CRD_ESTATE, "multi-slab context is not wired (crd_comm_attach_local / crd_comm_init_rccl)");
 	if (c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "LOCAL groups evaluate f through crd_group_rhs_device");
 	if (int rc = set_device(c)) return rc;
@@ -538,24 +586,38 @@ int crd_group_rhs_device(crd_ctx *const *ctxs, int n, double t, const void *cons
 	if (int rc = check_group(ctxs, n)) return rc;
 	if (!y || !ydot) return CRD_EINVAL;
 	if (n == 1) return crd_rhs_device(ctxs[0], t, y[0], ydot[0]);
+	// Exchange() (src/FHNmodel_torus.cpp:775-950): pack var0 of the first / last row -- and, for theta-blocks, of the first / last
+	// column -- of every block's vector, then every block pulls its four neighbours' strips (only var0 is ever read from them)
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = ctxs[k];
 		if (c->halo != CRD_HALO_LOCAL) return fail(ctxs[0], CRD_ESTATE, "group is not attached");
 		if (int rc = set_device(c)) return rc;
 		HIP_TRY(c, launch_aos_row_extract(c->p.precision, y[k], c->edge_lo, c->nx, 0, c->compute));
 		HIP_TRY(c, launch_aos_row_extract(c->p.precision, y[k], c->edge_hi, c->nx, c->nyl - 1, c->compute));
+		if (c->d0 > 1) HIP_TRY(c, launch_aos_cols_extract(c->p.precision, y[k], c->edge_col[0], c->edge_col[1], c->nx, c->nyl, c->compute));
 		HIP_TRY(c, hipEventRecord(c->ev_edges, c->compute));
 	}
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = ctxs[k];
-		crd_ctx *prev = ctxs[(k + n - 1) % n], *next = ctxs[(k + 1) % n];
 		if (int rc = set_device(c)) return rc;
-		const size_t bytes = (size_t)c->nx * c->real_size;
-		HIP_TRY(c, hipStreamWaitEvent(c->compute, prev->ev_edges, 0));
-		HIP_TRY(c, hipStreamWaitEvent(c->compute, next->ev_edges, 0));
-		HIP_TRY(c, hipMemcpyPeerAsync(c->ghost_lo, c->device, prev->edge_hi, prev->device, bytes, c->compute));
-		HIP_TRY(c, hipMemcpyPeerAsync(c->ghost_hi, c->device, next->edge_lo, next->device, bytes, c->compute));
-		HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorbing(c, t) ? 1 : 0, y[k], ydot[k], c->ghost_lo, c->ghost_hi, 0, c->nyl, c->compute));
+		if (c->d1 > 1) {
+			crd_ctx *prev = c->neighbour(0, -1), *next = c->neighbour(0, +1);
+			const size_t bytes = (size_t)c->nx * c->real_size;
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, prev->ev_edges, 0));
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, next->ev_edges, 0));
+			HIP_TRY(c, hipMemcpyPeerAsync(c->ghost_lo, c->device, prev->edge_hi, prev->device, bytes, c->compute));
+			HIP_TRY(c, hipMemcpyPeerAsync(c->ghost_hi, c->device, next->edge_lo, next->device, bytes, c->compute));
+		}
+		if (c->d0 > 1) {
+			crd_ctx *west = c->neighbour(-1, 0), *east = c->neighbour(+1, 0);
+			const size_t bytes = (size_t)c->nyl * c->real_size;
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, west->ev_edges, 0));
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, east->ev_edges, 0));
+			HIP_TRY(c, hipMemcpyPeerAsync(c->ghost_col[0], c->device, west->edge_col[1], west->device, bytes, c->compute));
+			HIP_TRY(c, hipMemcpyPeerAsync(c->ghost_col[1], c->device, east->edge_col[0], east->device, bytes, c->compute));
+		}
+		HIP_TRY(c, launch_rhs_aos(c->p.precision, c->desc, absorbing(c, t) ? 1 : 0, y[k], ydot[k], c->ghost_lo, c->ghost_hi, 0, c->nyl, c->compute, c->ghost_col[0],
+		                          c->ghost_col[1]));
 	}
 	// the edge buffers may be repacked by the next call only after every neighbour has copied them
 	for (int k = 0; k < n; k++) {

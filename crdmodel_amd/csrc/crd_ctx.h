@@ -99,9 +99,10 @@ struct StreamSet {
 struct crd_ctx {
 	crd_params p{};
 	crd_grid g{};
-	int slab = 0, n_slabs = 1, device = 0;
-	int64_t js = 0, je = 0;
-	int nx = 0, nyl = 0;
+	int slab = 0, n_slabs = 1, device = 0;  // slab = the block's rank c0 d1 + c1, n_slabs = d0 d1
+	int c0 = 0, d0 = 1, c1 = 0, d1 = 1;     // block (c0, c1) of a d0 x d1 decomposition; phi-slabs: d0 = 1, c1 = slab
+	int64_t is = 0, ie = 0, js = 0, je = 0;
+	int nx = 0, nyl = 0;                    // the block's own width and height (nx = nxl; g.nx is the grid's)
 	size_t real_size = 8;
 	size_t plane_bytes = 0;
 
@@ -116,6 +117,14 @@ struct crd_ctx {
 	size_t stage_bytes = 0;
 	void *ghost_lo = nullptr, *ghost_hi = nullptr;   // var0 of rows -1 / nyl for the AoS RHS (multi-slab)
 	void *edge_lo = nullptr, *edge_hi = nullptr;     // var0 of rows 0 / nyl-1 packed from an AoS vector
+	// theta-blocks (d0 > 1): var0 of the columns beside the block (ghost) and of its own first / last column (edge), nyl reals each,
+	// [0] = west, [1] = east -- per state plane for the staged stepper, one pair for the AoS RHS
+	void *gcol[NPLANES][2] = {}, *ecol[NPLANES][2] = {};
+	void *ghost_col[2] = {}, *edge_col[2] = {};
+	crd_ctx *neighbour(int dtheta, int dphi) const  // of a LOCAL group, periodic in both directions
+	{
+		return group[(size_t)(((c0 + dtheta + d0) % d0) * d1 + (c1 + dphi + d1) % d1)];
+	}
 	double *scalar_dev = nullptr;
 	double *err_partials = nullptr;  // adaptive stepping: per-item error sums (lazy)
 	int err_capacity = 0;
@@ -231,6 +240,9 @@ int check_group(crd_ctx *const *ctxs, int n);
 
 // crd_halo.cpp: fill ghost rows [-depth, 0) and [nyl, nyl + depth) of plane `plane_index` from the ring neighbours, on the comm streams
 int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_v);
+// ... 2-D blocks (LOCAL groups): one ghost row of var0 from the phi neighbours and one ghost column strip from the theta neighbours
+int exchange_block_input(crd_ctx *const *cs, int n, int plane_index);
+int prime_block_halo(crd_ctx *const *cs, int n, int plane_index);
 int prime_halo(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_v);
 
 // crd_steppers.cpp

@@ -26,7 +26,7 @@ template <typename Real>
 struct Slab {
 	const Real *cA, *cP, *brow;
 	Real cX, ka4;
-	int nx, nyl, wrap, has_row0, has_rowN, just_diffusion;
+	int nx, nyl, wrap, has_row0, has_rowN, just_diffusion, wrap_x;
 };
 
 template <typename Real>
@@ -44,6 +44,7 @@ inline Slab<Real> typed(const SlabDesc &d)
 	s.has_row0 = d.has_row0;
 	s.has_rowN = d.has_rowN;
 	s.just_diffusion = d.just_diffusion;
+	s.wrap_x = d.wrap_x;
 	return s;
 }
 

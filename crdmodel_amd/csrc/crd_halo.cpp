@@ -133,6 +133,60 @@ int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, 
 	return CRD_OK;
 }
 
+// 2-D blocks of a LOCAL group (staged stepper): var0 of plane `plane_index` -- one ghost row from each phi neighbour (when phi is
+// split) and one ghost column strip from each theta neighbour (when theta is), the four strips of the reference's Exchange()
+// (src/FHNmodel_torus.cpp:775-950; the 5-point stencil reads no corner).  Every context has recorded ev_edges behind the launch
+// that wrote the plane and behind the pack of its edge columns.
+int exchange_block_input(crd_ctx *const *cs, int n, int plane_index)
+{
+	TraceRange range("crd_halo_exchange(blocks)");
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_edges, 0));
+		if (c->d1 > 1) {
+			HIP_TRY(c, hipStreamWaitEvent(c->comm, c->neighbour(0, -1)->ev_edges, 0));
+			HIP_TRY(c, hipStreamWaitEvent(c->comm, c->neighbour(0, +1)->ev_edges, 0));
+		}
+		if (c->d0 > 1) {
+			HIP_TRY(c, hipStreamWaitEvent(c->comm, c->neighbour(-1, 0)->ev_edges, 0));
+			HIP_TRY(c, hipStreamWaitEvent(c->comm, c->neighbour(+1, 0)->ev_edges, 0));
+		}
+	}
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		if (c->d1 > 1) {
+			crd_ctx *prev = c->neighbour(0, -1), *next = c->neighbour(0, +1);
+			const size_t bytes = (size_t)c->nx * c->real_size;
+			void *mine = c->plane[plane_index][0];
+			HIP_TRY(c, hipMemcpyPeerAsync(c->row_ptr(mine, -1), c->device, prev->row_ptr(prev->plane[plane_index][0], prev->nyl - 1), prev->device, bytes, c->comm));
+			HIP_TRY(c, hipMemcpyPeerAsync(c->row_ptr(mine, c->nyl), c->device, next->row_ptr(next->plane[plane_index][0], 0), next->device, bytes, c->comm));
+		}
+		if (c->d0 > 1) {
+			crd_ctx *west = c->neighbour(-1, 0), *east = c->neighbour(+1, 0);
+			const size_t bytes = (size_t)c->nyl * c->real_size;
+			HIP_TRY(c, hipMemcpyPeerAsync(c->gcol[plane_index][0], c->device, west->ecol[plane_index][1], west->device, bytes, c->comm));
+			HIP_TRY(c, hipMemcpyPeerAsync(c->gcol[plane_index][1], c->device, east->ecol[plane_index][0], east->device, bytes, c->comm));
+		}
+		HIP_TRY(c, hipEventRecord(c->ev_halo, c->comm));
+	}
+	return CRD_OK;
+}
+
+// ... in front of a run's first stage: the edge columns of the resident state, then the exchange
+int prime_block_halo(crd_ctx *const *cs, int n, int plane_index)
+{
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (int rc = set_device(c)) return rc;
+		if (c->d0 > 1)
+			HIP_TRY(c, launch_plane_cols_extract(c->p.precision, c->plane[plane_index][0], c->ecol[plane_index][0], c->ecol[plane_index][1], c->nx, c->nyl, c->compute));
+		HIP_TRY(c, hipEventRecord(c->ev_edges, c->compute));
+	}
+	return exchange_block_input(cs, n, plane_index);
+}
+
 int prime_halo(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_v)
 {
 	for (int k = 0; k < n; k++) {

@@ -139,6 +139,29 @@ int crd_slab_extents(int64_t ny, int slab, int n_slabs, int64_t *js, int64_t *je
 	return CRD_OK;
 }
 
+int crd_dims_create(int nprocs, int *d0, int *d1)
+{
+	if (nprocs < 1 || !d0 || !d1) return CRD_EINVAL;
+	// MPI_Dims_create(nprocs, 2, dims) with dims = {0, 0} (src/FHNmodel_torus.cpp:726-728): the factor pair closest to a square, in
+	// non-increasing order -- 4 -> {2, 2}, 8 -> {4, 2}, 2 -> {2, 1}, 6 -> {3, 2}
+	int b = 1;
+	for (int f = 1; (long)f * f <= nprocs; f++)
+		if (nprocs % f == 0) b = f;
+	*d0 = nprocs / b;
+	*d1 = b;
+	return CRD_OK;
+}
+
+int crd_block_extents(int64_t nx, int64_t ny, int c0, int d0, int c1, int d1, int64_t *is, int64_t *ie, int64_t *js, int64_t *je)
+{
+	if (!is || !ie || !js || !je || d0 < 1 || d1 < 1 || c0 < 0 || c0 >= d0 || c1 < 0 || c1 >= d1 || nx < d0 || ny < d1) return CRD_EINVAL;
+	*is = nx * c0 / d0;            // src/FHNmodel_torus.cpp:750
+	*ie = nx * (c0 + 1) / d0 - 1;  // :751
+	*js = ny * c1 / d1;            // :752
+	*je = ny * (c1 + 1) / d1 - 1;  // :753
+	return CRD_OK;
+}
+
 int crd_halo_plan(int slab, int n_slabs, int64_t nyl, int depth, crd_halo_op ops[4])
 {
 	if (!ops || n_slabs < 1 || slab < 0 || slab >= n_slabs || depth < 1 || nyl < depth) return CRD_EINVAL;
@@ -230,12 +253,21 @@ int crd_steady_state_as_printed(int model, double beta, int decimals, double *s0
 
 int crd_initial_conditions(const crd_run_config *cfg, int64_t js, int64_t je, double *y_aos)
 {
+	if (!cfg) return CRD_EINVAL;
+	crd_grid g;
+	const int rc = crd_grid_from_params(&cfg->params, &g);
+	if (rc != CRD_OK) return rc;
+	return crd_initial_conditions_block(cfg, 0, g.nx - 1, js, je, y_aos);
+}
+
+int crd_initial_conditions_block(const crd_run_config *cfg, int64_t is, int64_t ie, int64_t js, int64_t je, double *y_aos)
+{
 	if (!cfg || !y_aos) return CRD_EINVAL;
 	const crd_params &p = cfg->params;
 	crd_grid g;
 	int rc = crd_grid_from_params(&p, &g);
 	if (rc != CRD_OK) return rc;
-	if (js < 0 || je < js || je >= g.ny) return CRD_EINVAL;
+	if (js < 0 || je < js || je >= g.ny || is < 0 || ie < is || ie >= g.nx) return CRD_EINVAL;
 	// The stable state enters only the rules that start from it (the reference computes Us, Vs / reads Zs, Ys for these
 	// and never touches them under the uniform and varyBeta rules, so an unused `beta` without a fixed point must not matter).
 	const bool needs_steady = (p.model == CRD_MODEL_FHN) ? !((p.surface == CRD_SURFACE_TORUS) ? (p.vary_beta != 0) : (p.vary_beta == 1))
@@ -309,11 +341,12 @@ int crd_initial_conditions(const crd_run_config *cfg, int64_t js, int64_t je, do
 		theta_in[(size_t)i] = (wraps && !theta_and_only) ? (xx >= x_lo || xx <= x_hi) : (xx >= x_lo && xx <= x_hi);
 	}
 	if (rule == RAND) srand(1);  // every reference rank starts from the default seed
+	const int64_t nxl = ie - is + 1;
 	for (int64_t j = js; j <= je; j++) {
 		const double yy = g.ymin + (double)j * g.dy;
 		const bool phi_in = yy >= phi_lo_mult * wave_length && yy <= (phi_lo_mult + 1.0) * wave_length;
-		double *row = y_aos + 2 * nx * (j - js);
-		for (int64_t i = 0; i < nx; i++) {
+		double *row = y_aos + 2 * nxl * (j - js) - 2 * is;  // (indexed by the global column below)
+		for (int64_t i = is; i <= ie; i++) {
 			double a = base0, b = base1;
 			if (rule == RECT && phi_in && theta_in[(size_t)i]) {
 				a = pert0;

@@ -310,15 +310,21 @@ int usable_threads()
 
 extern "C" int crd_writer_open(const crd_run_config *cfg, const char *dir, int slab, int n_slabs, crd_writer **out)
 {
+	return crd_writer_open_block(cfg, dir, slab, 0, 1, slab, n_slabs, out);
+}
+
+extern "C" int crd_writer_open_block(const crd_run_config *cfg, const char *dir, int rank, int c0, int d0, int c1, int d1, crd_writer **out)
+{
 	if (!cfg || !out) return CRD_EINVAL;
 	*out = nullptr;
 	crd_grid g;
 	int rc = crd_grid_from_params(&cfg->params, &g);
 	if (rc != CRD_OK) return rc;
-	int64_t js, je;
-	rc = crd_slab_extents(g.ny, slab, n_slabs, &js, &je);
+	int64_t is, ie, js, je;
+	rc = crd_block_extents(g.nx, g.ny, c0, d0, c1, d1, &is, &ie, &js, &je);
 	if (rc != CRD_OK) return rc;
-	if (slab > 999) return CRD_EINVAL;
+	const int slab = rank;
+	if (slab < 0 || slab > 999) return CRD_EINVAL;
 
 	const std::string base = std::string(dir && *dir ? dir : ".") + "/" + crd::model_name(cfg->params.model) + "_" +
 	                         crd::surface_name(cfg->params.surface) + "_";
@@ -327,13 +333,13 @@ extern "C" int crd_writer_open(const crd_run_config *cfg, const char *dir, int s
 
 	FILE *fs = std::fopen((base + "subdomain" + tag).c_str(), "w");
 	if (!fs) return CRD_EIO;
-	std::fprintf(fs, "%li  %li  %li  %li  %li  %li %f %f %f\n", (long)g.nx, (long)g.ny, 0L, (long)(g.nx - 1), (long)js, (long)je,
+	std::fprintf(fs, "%li  %li  %li  %li  %li  %li %f %f %f\n", (long)g.nx, (long)g.ny, (long)is, (long)ie, (long)js, (long)je,
 	             g.xmin, g.xmax, cfg->t_final);
 	std::fclose(fs);
 
 	crd_writer *w = new (std::nothrow) crd_writer;
 	if (!w) return CRD_ENOMEM;
-	w->nxl = g.nx;
+	w->nxl = ie - is + 1;
 	w->nyl = je - js + 1;
 	w->all_vars = (cfg->include_all_vars == 1);
 	w->threads = usable_threads();

@@ -25,6 +25,8 @@ struct SlabDesc {
 	int nx;
 	int nyl;
 	int wrap;          // 1: single slab, phi neighbours wrap inside the slab; 0: read ghost rows
+	int wrap_x = 1;    // 1: the context spans all of theta, column -1 is column nx-1; 0: a theta-block of a 2-D decomposition --
+	                   // the columns beside the block come from ghost-column strips (staged kernels / f() only)
 	int has_row0;      // slab owns global row 0      (js == 0)
 	int has_rowN;      // slab owns global row ny-1   (je == ny-1)
 	int js;            // global index of local row 0
@@ -41,13 +43,15 @@ struct StageCall {
 	Planes y0;       // state at the start of the step (stages 1-3)
 	Planes acc;      // running combination (stages 1-4)
 	Planes yout;     // stage output (next stage's input; stage 4: the new state; stage 0: ydot)
+	// theta-blocks (SlabDesc::wrap_x = 0): var0 of the columns west / east of the block for the rows of yin, nyl reals each
+	const void *gcol_w = nullptr, *gcol_e = nullptr;
 };
 
 // One evaluation of f on AoS device vectors (the ARKRhsFn boundary): y, ydot are [nyl][nx][2];
 // ghost_lo / ghost_hi hold var0 of rows -1 and nyl (ignored when d.wrap).  Rows [row_begin, row_end) are produced; rows
 // row_begin-1 and row_end of y must be resident as well (the pipelined host path computes band by band).
 hipError_t launch_rhs_aos(int precision, const SlabDesc &d, int absorb, const void *y, void *ydot, const void *ghost_lo,
-                          const void *ghost_hi, int row_begin, int row_end, hipStream_t s);
+                          const void *ghost_hi, int row_begin, int row_end, hipStream_t s, const void *gcol_w = nullptr, const void *gcol_e = nullptr);
 
 // One RK4 stage (or a bare RHS) on SoA planes, rows [row_begin, row_end) of the slab.
 hipError_t launch_stage(int precision, const SlabDesc &d, const StageCall &c, int row_begin, int row_end, hipStream_t s);
@@ -97,6 +101,10 @@ hipError_t launch_aos_to_planes(int precision, int src_is_f64, const void *aos, 
 hipError_t launch_planes_to_aos(int precision, int dst_is_f64, Planes src, void *aos, int nx, int nyl, hipStream_t s);
 // Extract var0 of one AoS row into a contiguous row (halo packing for crd_rhs_*).
 hipError_t launch_aos_row_extract(int precision, const void *aos, void *row, int nx, int j, hipStream_t s);
+// var0 of the first and the last column (rows 0 .. nyl-1) into two contiguous strips: from an AoS vector / from a field plane
+// (the E / W strips of Exchange(), src/FHNmodel_torus.cpp:854-876, for theta-blocks).
+hipError_t launch_aos_cols_extract(int precision, const void *aos, void *col_w, void *col_e, int nx, int nyl, hipStream_t s);
+hipError_t launch_plane_cols_extract(int precision, const void *u_plane, void *col_w, void *col_e, int nx, int nyl, hipStream_t s);
 
 // out = cubic Hermite interpolant at t_n + theta h of the step (yn, fn) -> (yp, fp); owned rows of both fields.
 hipError_t launch_hermite(int precision, Planes yn, Planes yp, Planes fn, Planes fp, Planes out, int nx, int nyl, double theta, double h, hipStream_t s);

@@ -29,6 +29,7 @@ struct StageArgs {
 	Real *out_u, *out_v;        // stage output
 	Real h_out, h_acc;          // yout = y0 + h_out k ; acc (+)= h_acc k
 	int absorb;
+	const Real *gw, *ge;        // theta-blocks: the input's columns west / east of the block, by local row
 };
 
 // RK4 stage kernel on SoA planes.  STAGE 0 writes k = f(yin); stages 1-4 follow SURVEY 8(d)'s scheme:
@@ -63,8 +64,9 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, S
 			const Real *row = a.in_u + off;
 			uC[r] = row[i];
 			vC[r] = a.in_v[off + i];
-			if (tx == 0) tile[ty + kBY * r + 1][0] = row[iw];
-			if (last_col) tile[ty + kBY * r + 1][tx + 2] = row[ie];
+			// (theta-blocks: beyond the block's first / last column lie the neighbour blocks' columns, exchanged into strips)
+			if (tx == 0) tile[ty + kBY * r + 1][0] = (i0 == 0 && !s.wrap_x) ? a.gw[j] : row[iw];
+			if (last_col) tile[ty + kBY * r + 1][tx + 2] = (i == nx - 1 && !s.wrap_x) ? a.ge[j] : row[ie];
 			if (STAGE == 2 || STAGE == 3) {
 				p0u[r] = a.y0_u[off + i];
 				p0v[r] = a.y0_v[off + i];
@@ -121,8 +123,8 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, S
 template <typename Real, int MODEL>
 __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, const typename Pair<Real>::type *__restrict__ y,
                                                                typename Pair<Real>::type *__restrict__ ydot, const Real *__restrict__ ghost_lo,
-                                                               const Real *__restrict__ ghost_hi, int absorb, int row_begin, int row_end, int nbx,
-                                                               int nblocks)
+                                                               const Real *__restrict__ ghost_hi, const Real *__restrict__ gcol_w,
+                                                               const Real *__restrict__ gcol_e, int absorb, int row_begin, int row_end, int nbx, int nblocks)
 {
 	using P = typename Pair<Real>::type;
 	__shared__ Real tile[kTY + 2][kTX + 2];
@@ -146,8 +148,8 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, con
 		if (j < row_end && col_ok) {
 			const P *row = y + (size_t)j * nx;
 			own[r] = row[i];
-			if (tx == 0) tile[ty + kBY * r + 1][0] = row[iw].x;
-			if (last_col) tile[ty + kBY * r + 1][tx + 2] = row[ie].x;
+			if (tx == 0) tile[ty + kBY * r + 1][0] = (i0 == 0 && !s.wrap_x) ? gcol_w[j] : row[iw].x;
+			if (last_col) tile[ty + kBY * r + 1][tx + 2] = (i == nx - 1 && !s.wrap_x) ? gcol_e[j] : row[ie].x;
 		}
 		if (j < row_end && col_ok) tile[ty + kBY * r + 1][tx + 1] = own[r].x;
 	}
@@ -203,6 +205,18 @@ __global__ void __launch_bounds__(256) crd_aos_row_extract_kernel(const Real *__
 	if (i < nx) row[i] = aos_row[2 * (size_t)i];
 }
 
+// column 0 and column nx-1 of rows 0 .. nyl-1 (element stride `stride` reals: 1 for a plane, 2 for var0 of an AoS vector)
+template <typename Real>
+__global__ void __launch_bounds__(256) crd_cols_extract_kernel(const Real *__restrict__ base, Real *__restrict__ col_w, Real *__restrict__ col_e, int nx, int nyl, int stride)
+{
+	const int j = blockIdx.x * blockDim.x + threadIdx.x;
+	if (j < nyl) {
+		const size_t row = (size_t)j * (size_t)nx * (size_t)stride;
+		col_w[j] = base[row];
+		col_e[j] = base[row + (size_t)(nx - 1) * (size_t)stride];
+	}
+}
+
 template <typename Real>
 __global__ void __launch_bounds__(256) crd_max_abs_kernel(const Real *__restrict__ u, size_t n, double *out)
 {
@@ -242,6 +256,9 @@ hipError_t launch_stage_t(const SlabDesc &d, const StageCall &c, int row_begin, 
 	a.out_u = row0<Real>(c.yout.u, d.nx);
 	a.out_v = row0<Real>(c.yout.v, d.nx);
 	a.absorb = c.absorb;
+	a.gw = static_cast<const Real *>(c.gcol_w);
+	a.ge = static_cast<const Real *>(c.gcol_e);
+	if (!d.wrap_x && (!a.gw || !a.ge)) return hipErrorInvalidValue;
 	switch (c.stage) {
 	case 1: a.h_out = (Real)(0.5 * c.dt); a.h_acc = (Real)(c.dt / 6.0); break;
 	case 2: a.h_out = (Real)(0.5 * c.dt); a.h_acc = (Real)(c.dt / 3.0); break;
@@ -266,17 +283,18 @@ hipError_t launch_stage_t(const SlabDesc &d, const StageCall &c, int row_begin, 
 
 template <typename Real, int MODEL>
 hipError_t launch_rhs_aos_t(const SlabDesc &d, int absorb, const void *y, void *ydot, const void *glo, const void *ghi, int row_begin, int row_end,
-                            hipStream_t st)
+                            hipStream_t st, const void *gw, const void *ge)
 {
 	clear_launch_status();
 	if (row_end <= row_begin) return hipSuccess;
+	if (!d.wrap_x && (!gw || !ge)) return hipErrorInvalidValue;
 	using P = typename Pair<Real>::type;
 	const Slab<Real> s = typed<Real>(d);
 	const int nbx = (d.nx + kTX - 1) / kTX, nby = (row_end - row_begin + kTY - 1) / kTY;
 	const int nblocks = nbx * nby;
 	crd_rhs_aos_kernel<Real, MODEL><<<nblocks, dim3(kTX, kBY), 0, st>>>(s, static_cast<const P *>(y), static_cast<P *>(ydot),
-	                                                                  static_cast<const Real *>(glo), static_cast<const Real *>(ghi), absorb, row_begin,
-	                                                                  row_end, nbx, nblocks);
+	                                                                  static_cast<const Real *>(glo), static_cast<const Real *>(ghi), static_cast<const Real *>(gw),
+	                                                                  static_cast<const Real *>(ge), absorb, row_begin, row_end, nbx, nblocks);
 	return launch_status();
 }
 
@@ -299,14 +317,14 @@ hipError_t launch_stage(int precision, const SlabDesc &d, const StageCall &c, in
 const char *stage_kernel_name(int, int) { return "crd_rk4_stage_kernel"; }
 
 hipError_t launch_rhs_aos(int precision, const SlabDesc &d, int absorb, const void *y, void *ydot, const void *ghost_lo, const void *ghost_hi,
-                          int row_begin, int row_end, hipStream_t s)
+                          int row_begin, int row_end, hipStream_t s, const void *gcol_w, const void *gcol_e)
 {
 	const int model = kernel_model(d);
 #define CRD_AOS_DISPATCH(REAL)                                                                                                               \
 	switch (model) {                                                                                                                         \
-	case CRD_MODEL_FHN: return launch_rhs_aos_t<REAL, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s);         \
-	case CRD_MODEL_GOLDBETER: return launch_rhs_aos_t<REAL, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s); \
-	default: return launch_rhs_aos_t<REAL, kModelDiffusionOnly>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s);              \
+	case CRD_MODEL_FHN: return launch_rhs_aos_t<REAL, CRD_MODEL_FHN>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s, gcol_w, gcol_e);         \
+	case CRD_MODEL_GOLDBETER: return launch_rhs_aos_t<REAL, CRD_MODEL_GOLDBETER>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s, gcol_w, gcol_e); \
+	default: return launch_rhs_aos_t<REAL, kModelDiffusionOnly>(d, absorb, y, ydot, ghost_lo, ghost_hi, row_begin, row_end, s, gcol_w, gcol_e);              \
 	}
 	if (precision == CRD_PRECISION_F64) CRD_AOS_DISPATCH(double)
 	CRD_AOS_DISPATCH(float)
@@ -494,6 +512,27 @@ hipError_t launch_ydd_sumsq(int precision, Planes y, Planes f0, Planes f2, doubl
 	clear_launch_status();
 	return precision == CRD_PRECISION_F64 ? launch_hin_ops_t<double>(2, y, f0, f2, nx, nyl, h, rtol, atol, partials_dev, out_dev, s)
 	                                      : launch_hin_ops_t<float>(2, y, f0, f2, nx, nyl, h, rtol, atol, partials_dev, out_dev, s);
+}
+
+hipError_t launch_aos_cols_extract(int precision, const void *aos, void *col_w, void *col_e, int nx, int nyl, hipStream_t s)
+{
+	clear_launch_status();
+	if (nyl <= 0) return hipSuccess;
+	const int g = (nyl + 255) / 256;
+	if (precision == CRD_PRECISION_F64) crd_cols_extract_kernel<double><<<g, 256, 0, s>>>(static_cast<const double *>(aos), static_cast<double *>(col_w), static_cast<double *>(col_e), nx, nyl, 2);
+	else crd_cols_extract_kernel<float><<<g, 256, 0, s>>>(static_cast<const float *>(aos), static_cast<float *>(col_w), static_cast<float *>(col_e), nx, nyl, 2);
+	return launch_status();
+}
+
+hipError_t launch_plane_cols_extract(int precision, const void *u_plane, void *col_w, void *col_e, int nx, int nyl, hipStream_t s)
+{
+	clear_launch_status();
+	if (nyl <= 0) return hipSuccess;
+	const int g = (nyl + 255) / 256;
+	if (precision == CRD_PRECISION_F64)
+		crd_cols_extract_kernel<double><<<g, 256, 0, s>>>(row0<double>(const_cast<void *>(u_plane), nx), static_cast<double *>(col_w), static_cast<double *>(col_e), nx, nyl, 1);
+	else crd_cols_extract_kernel<float><<<g, 256, 0, s>>>(row0<float>(const_cast<void *>(u_plane), nx), static_cast<float *>(col_w), static_cast<float *>(col_e), nx, nyl, 1);
+	return launch_status();
 }
 
 hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s)

@@ -34,6 +34,8 @@ struct Options {
 	bool binary = false;       // also write <Model>_<surface>_<var>.NNN.npy (crd_npy_writer)
 	bool binary_only = false;  // ... and no text rows (the text files are created empty; only crdmodel_amd.post reads such a run)
 	bool ref_steady_state = false;  // Goldbeter rest state as the reference reads it from its script's print (8 decimals)
+	int d0 = 0, d1 = 0;  // --decomp d0xd1: the reference's 2-D block layout (theta x phi) instead of phi-slabs; "--decomp mpi" = MPI_Dims_create(gpus)
+	bool decomp_mpi = false;
 };
 
 [[noreturn]] void usage(const char *argv0, bool alias)
@@ -43,7 +45,8 @@ struct Options {
 	} else {
 		std::cerr << "Usage: " << argv0
 		          << " --model fhn|goldbeter --surface torus|flat [--gpus G] [--devices D] [--dt DT] [--stepper auto|staged|fused]\n"
-		             "       [--precision 64|32] [--adaptive|--adaptive-rk43|--fixed] [--binary|--binary-only] [--ref-steady-state] [--outdir DIR] [--quiet]\n"
+		             "       [--precision 64|32] [--adaptive|--adaptive-rk43|--fixed] [--binary|--binary-only] [--ref-steady-state] [--decomp D0xD1|mpi]\n"
+		             "       [--outdir DIR] [--quiet]\n"
 		             "       <Config file path>\n";
 	}
 	std::exit(EXIT_FAILURE);
@@ -58,7 +61,7 @@ bool preset_from_name(const std::string &base, Options *o)
 	return false;
 }
 
-void banner(const crd_run_config &cfg, const crd_grid &g, int n_slabs, int64_t nyl0, double s0, double s1, double dt, int64_t steps_per_output)
+void banner(const crd_run_config &cfg, const crd_grid &g, int n_slabs, int64_t nxl0, int64_t nyl0, double s0, double s1, double dt, int64_t steps_per_output)
 {
 	// Same lines as src/FHNmodel_torus.cpp:249-275 (and the Goldbeter variant, src/GoldbeterModel_torus.cpp:266-303),
 	// with rtol / atol replaced by the fixed step.
@@ -68,7 +71,7 @@ void banner(const crd_run_config &cfg, const crd_grid &g, int n_slabs, int64_t n
 	std::cout << "   nprocs = " << n_slabs << "\n";
 	std::cout << "   nx = " << g.nx << "\n";
 	std::cout << "   ny = " << g.ny << "\n";
-	std::cout << "   nxl = " << g.nx << "\n";
+	std::cout << "   nxl = " << nxl0 << "\n";
 	std::cout << "   nyl = " << nyl0 << "\n";
 	std::cout << "   Diff = " << p.diffusion << "\n";
 	std::cout << "   Tfinal = " << cfg.t_final << "\n";
@@ -178,6 +181,11 @@ int main(int argc, char *argv[])
 			else if (s == "--binary") o.binary = true;
 			else if (s == "--binary-only") o.binary = o.binary_only = true;
 			else if (s == "--ref-steady-state") o.ref_steady_state = true;
+			else if (s == "--decomp") {
+				const std::string v = next();
+				if (v == "mpi") o.decomp_mpi = true;
+				else if (std::sscanf(v.c_str(), "%dx%d", &o.d0, &o.d1) != 2 || o.d0 < 1 || o.d1 < 1) usage(argv[0], false);
+			}
 			else if (s == "--precision") {
 				const std::string v = next();
 				o.precision = v == "32" ? CRD_PRECISION_F32 : v == "64" ? CRD_PRECISION_F64 : -2;
@@ -223,7 +231,20 @@ int main(int argc, char *argv[])
 
 	crd_grid g;
 	if ((rc = crd_grid_from_params(&cfg.params, &g)) != CRD_OK) return die("crd_grid_from_params", rc, nullptr);
-	const int G = cfg.n_gpus;
+	// Decomposition: phi-slabs (1 x G: the layout for one node, and the one the one-launch stepper needs) unless the reference's
+	// own 2-D blocks are asked for -- `--decomp 2x2`, or `--decomp mpi` = what MPI_Dims_create makes of the slab count
+	// (src/FHNmodel_torus.cpp:724-728: `mpirun -np 4` is 2 x 2) -- which step with the staged kernels.
+	int d0 = 1, d1 = cfg.n_gpus;
+	if (o.decomp_mpi) crd_dims_create(cfg.n_gpus, &d0, &d1);
+	else if (o.d0 > 0) {
+		d0 = o.d0;
+		d1 = o.d1;
+	}
+	const int G = d0 * d1;
+	if (d0 > 1 && (cfg.adaptive || o.binary)) {
+		std::cerr << "\nCRD_ERROR: theta-blocks (--decomp with more than one theta-block) step with the fixed-step staged RK4 and write text files only\n\n";
+		return 1;
+	}
 	const int ndev = o.devices > 0 ? o.devices : G;
 
 	double s0 = 0, s1 = 0;  // banner only, and only printed for a constant beta (src/FHNmodel_torus.cpp:268-271)
@@ -260,7 +281,7 @@ int main(int argc, char *argv[])
 		for (auto *c : ctx) crd_destroy(c);
 	};
 	for (int k = 0; k < G; k++) {
-		if ((rc = crd_create(&cfg.params, k, G, k % ndev, &ctx[(size_t)k])) != CRD_OK) {
+		if ((rc = crd_create_block(&cfg.params, k / d1, d0, k % d1, d1, k % ndev, &ctx[(size_t)k])) != CRD_OK) {
 			die("crd_create", rc, nullptr);
 			cleanup();
 			return 1;
@@ -273,17 +294,17 @@ int main(int argc, char *argv[])
 		return 1;
 	}
 
-	int64_t js0 = 0, je0 = 0;
-	crd_get_slab(ctx[0], &js0, &je0);
-	if (!o.quiet) banner(cfg, g, G, je0 - js0 + 1, s0, s1, dt, steps_per_output);
+	int64_t is0 = 0, ie0 = 0, js0 = 0, je0 = 0;
+	crd_get_block(ctx[0], &is0, &ie0, &js0, &je0);
+	if (!o.quiet) banner(cfg, g, G, ie0 - is0 + 1, je0 - js0 + 1, s0, s1, dt, steps_per_output);
 
 	// Initial conditions, subdomain files, first output row (src/FHNmodel_torus.cpp:285-354,376-410).
 	for (int k = 0; k < G; k++) {
-		int64_t js, je;
-		crd_get_slab(ctx[(size_t)k], &js, &je);
-		host[(size_t)k].resize((size_t)(2 * g.nx * (je - js + 1)));
+		int64_t is, ie, js, je;
+		crd_get_block(ctx[(size_t)k], &is, &ie, &js, &je);
+		host[(size_t)k].resize((size_t)(2 * (ie - is + 1) * (je - js + 1)));
 		host_b[(size_t)k].resize(host[(size_t)k].size());
-		if ((rc = crd_initial_conditions(&cfg, js, je, host[(size_t)k].data())) != CRD_OK) {
+		if ((rc = crd_initial_conditions_block(&cfg, is, ie, js, je, host[(size_t)k].data())) != CRD_OK) {
 			die("crd_initial_conditions", rc, nullptr);
 			cleanup();
 			return 1;
@@ -293,7 +314,7 @@ int main(int argc, char *argv[])
 			cleanup();
 			return 1;
 		}
-		if ((rc = crd_writer_open(&cfg, o.outdir.c_str(), k, G, &wr[(size_t)k])) != CRD_OK ||
+		if ((rc = crd_writer_open_block(&cfg, o.outdir.c_str(), k, k / d1, d0, k % d1, d1, &wr[(size_t)k])) != CRD_OK ||
 		    (!o.binary_only && (rc = crd_writer_write_row(wr[(size_t)k], host[(size_t)k].data())) != CRD_OK)) {
 			die("crd_writer", rc, nullptr);
 			cleanup();

@@ -85,6 +85,31 @@ int staged_step_multi(crd_ctx *const *cs, int n, double t, double dt, bool timed
 	return CRD_OK;
 }
 
+// 2-D blocks (theta split: a LOCAL group driven by one thread).  Per stage: [wait halo(in)] all rows of the block -> pack the
+// output's edge columns -> record edges; then every block pulls one ghost row / column strip of the output from its neighbours.
+// No boundary / interior overlap here: the layout exists to reproduce the reference's `-np 4` file for file, the fast layout on
+// one node is phi-slabs.
+int staged_step_blocks(crd_ctx *const *cs, int n, double t, double dt)
+{
+	for (int stage = 1; stage <= 4; stage++) {
+		const StagePlan &sp = kStages[stage - 1];
+		for (int k = 0; k < n; k++) {
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			StageCall call = make_stage_call(c, stage, t, dt);
+			call.gcol_w = c->gcol[sp.in][0];
+			call.gcol_e = c->gcol[sp.in][1];
+			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+			HIP_TRY(c, launch_stage(c->p.precision, c->desc, call, 0, c->nyl, c->compute));
+			if (c->d0 > 1)
+				HIP_TRY(c, launch_plane_cols_extract(c->p.precision, c->plane[sp.out][0], c->ecol[sp.out][0], c->ecol[sp.out][1], c->nx, c->nyl, c->compute));
+			HIP_TRY(c, hipEventRecord(c->ev_edges, c->compute));
+		}
+		if (int rc = exchange_block_input(cs, n, sp.out)) return rc;
+	}
+	return CRD_OK;
+}
+
 // Fused stepper on several slabs: ONE exchange every kExchangeEvery steps, kGhost = 4 * kExchangeEvery ghost rows of both
 // fields.  Step q of a cycle (q = 0 right after an exchange) produces rows [-e, nyl + e) with e = 4 (kExchangeEvery-1-q):
 // the still-valid part of the ghost region is recomputed redundantly (same kernel, same inputs, so bit-identical to what
@@ -352,6 +377,21 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		if (resolve_stepper(cs[k]) != stepper) return fail(lead, CRD_EINVAL, "contexts of one run disagree on the stepper");
 	int timed = 0;
 	const bool single = (lead->halo == CRD_HALO_SELF);
+	if (lead->d0 > 1) {
+		// theta-blocks: staged kernels, every block of the run in this one call
+		if (lead->halo != CRD_HALO_LOCAL || n != lead->n_slabs) return fail(lead, CRD_ESTATE, "theta-blocks step as a LOCAL group holding every block of the run");
+		for (int k = 0; k < n; k++) cs[k]->cycle_pos = -1;
+		if (nsteps > 0)
+			if (int rc = prime_block_halo(cs, n, crd_ctx::Y)) return rc;
+		for (int64_t s = 0; s < nsteps; s++)
+			if (int rc = staged_step_blocks(cs, n, t0 + (double)s * dt, dt)) return rc;
+		for (int k = 0; k < n; k++) {
+			if (int rc = set_device(cs[k])) return rc;
+			HIP_TRY(cs[k], hipStreamWaitEvent(cs[k]->compute, cs[k]->ev_halo, 0));
+		}
+		if (timed_launches) *timed_launches = 0;
+		return CRD_OK;
+	}
 	if (single) {
 		crd_ctx *c = lead;
 		if (int rc = set_device(c)) return rc;
@@ -516,6 +556,7 @@ int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_
 		for (int k = 1; k < n; k++)
 			if (ctxs[k]->device != ctxs[k - 1]->device) first.push_back(k);
 	}
+	if (ctxs[0]->d0 > 1) first.assign(1, 0);  // theta-blocks: one issuing thread
 	const int nthreads = (int)first.size();
 	decide_cycle_start(ctxs, n);
 	TraceRange range("crd_group_step_rk4");
@@ -697,6 +738,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	    !(o.shrink > 0.0 && o.shrink < 1.0) || o.max_steps < 1 || !(o.h0 >= 0.0) || std::isnan(o.h_max) || !std::isfinite(t0) || !std::isfinite(tout) || tout < t0 ||
 	    (o.method != CRD_ADAPT_RK43 && o.method != CRD_ADAPT_ARKODE))
 		return fail(lead, CRD_EINVAL, "bad adaptive options / time interval");
+	if (lead->d0 > 1) return fail(lead, CRD_EINVAL, "the error-controlled integrators need phi-slabs (theta-blocks step with the staged RK4 only)");
 	const bool multi = lead->halo != CRD_HALO_SELF;
 	const bool arkode_method = o.method == CRD_ADAPT_ARKODE;
 	const bool dense = o.dense_output != 0 || arkode_method;  // ARKode's ARK_NORMAL never shortens a step for an output time

@@ -40,6 +40,20 @@ def slab_extents(ny, slab, n_slabs):
     return js.value, je.value
 
 
+def dims_create(nprocs):
+    """MPI_Dims_create(nprocs, 2): the reference's process grid (d0 theta-blocks x d1 phi-blocks)."""
+    d0, d1 = C.c_int(), C.c_int()
+    check(lib().crd_dims_create(nprocs, C.byref(d0), C.byref(d1)), "crd_dims_create")
+    return d0.value, d1.value
+
+
+def block_extents(nx, ny, c0, d0, c1, d1):
+    """(is, ie, js, je) of block (c0, c1) of a d0 x d1 decomposition (SetupDecomp)."""
+    v = [C.c_int64() for _ in range(4)]
+    check(lib().crd_block_extents(nx, ny, c0, d0, c1, d1, *[C.byref(x) for x in v]), "crd_block_extents")
+    return tuple(x.value for x in v)
+
+
 def halo_plan(slab, n_slabs, nyl, depth=1):
     """The four ordered point-to-point operations of one halo exchange: [(is_send, peer, row_begin, row_count)]."""
     ops = (capi.HaloOp * 4)()
@@ -103,22 +117,28 @@ def run_config(params, *, wave_length=0.1, wave_width=0.5, wave_inside=0, output
     return cfg
 
 
-def initial_conditions(cfg, js=None, je=None):
-    """Rows [js, je] of the reference's initial state as float64 (nyl, nx, 2)."""
+def initial_conditions(cfg, js=None, je=None, is_=None, ie=None):
+    """Rows [js, je] (and columns [is_, ie]) of the reference's initial state as float64 (nyl, nxl, 2)."""
     g = grid_of(cfg.params)
     js = 0 if js is None else js
     je = g.ny - 1 if je is None else je
-    y = np.empty((je - js + 1, g.nx, 2), dtype=np.float64)
-    check(lib().crd_initial_conditions(C.byref(cfg), js, je, y.ctypes.data), "crd_initial_conditions")
+    is_ = 0 if is_ is None else is_
+    ie = g.nx - 1 if ie is None else ie
+    y = np.empty((je - js + 1, ie - is_ + 1, 2), dtype=np.float64)
+    check(lib().crd_initial_conditions_block(C.byref(cfg), is_, ie, js, je, y.ctypes.data), "crd_initial_conditions_block")
     return y
 
 
 class Writer:
     """Per-subdomain text files in the reference's format (/root/reference/src/FHNmodel_torus.cpp:376-410,438-455)."""
 
-    def __init__(self, cfg, directory, slab=0, n_slabs=1):
+    def __init__(self, cfg, directory, slab=0, n_slabs=1, block=None):
         self._h = C.c_void_p()
-        check(lib().crd_writer_open(C.byref(cfg), str(directory).encode(), slab, n_slabs, C.byref(self._h)), "crd_writer_open")
+        if block is None:
+            check(lib().crd_writer_open(C.byref(cfg), str(directory).encode(), slab, n_slabs, C.byref(self._h)), "crd_writer_open")
+        else:  # block = (c0, d0, c1, d1); the file number is the block's rank
+            c0, d0, c1, d1 = block
+            check(lib().crd_writer_open_block(C.byref(cfg), str(directory).encode(), c0 * d1 + c1, c0, d0, c1, d1, C.byref(self._h)), "crd_writer_open_block")
 
     def write_row(self, y):
         y = np.ascontiguousarray(y, dtype=np.float64)
@@ -156,10 +176,15 @@ def _adaptive_result(rc, st, where, handle):
 class Slab:
     """One phi-slab of the grid resident on one GPU (crd_ctx)."""
 
-    def __init__(self, params, slab=0, n_slabs=1, device=0):
+    def __init__(self, params, slab=0, n_slabs=1, device=0, block=None):
         self._h = C.c_void_p()
         self.params = params
-        rc = lib().crd_create(C.byref(params), slab, n_slabs, device, C.byref(self._h))
+        if block is None:
+            rc = lib().crd_create(C.byref(params), slab, n_slabs, device, C.byref(self._h))
+        else:  # block = (c0, d0, c1, d1) of a 2-D decomposition
+            c0, d0, c1, d1 = block
+            slab, n_slabs = c0 * d1 + c1, d0 * d1
+            rc = lib().crd_create_block(C.byref(params), c0, d0, c1, d1, device, C.byref(self._h))
         if rc != capi.OK:
             self._h = None
             raise CrdError(rc, "crd_create", lib().crd_last_error(None).decode())
@@ -169,7 +194,10 @@ class Slab:
         js, je = C.c_int64(), C.c_int64()
         check(lib().crd_get_slab(self._h, C.byref(js), C.byref(je)), "crd_get_slab", self._h)
         self.js, self.je = js.value, je.value
-        self.nx, self.nyl = g.nx, je.value - js.value + 1
+        blk = [C.c_int64() for _ in range(4)]
+        check(lib().crd_get_block(self._h, *[C.byref(x) for x in blk]), "crd_get_block", self._h)
+        self.is_, self.ie = blk[0].value, blk[1].value
+        self.nx, self.nyl = self.ie - self.is_ + 1, je.value - js.value + 1
         self.slab, self.n_slabs = slab, n_slabs
         self.dtype = np.float64 if params.precision == PRECISION_F64 else np.float32
 
@@ -343,31 +371,44 @@ def rccl_unique_id():
 
 
 class LocalGroup:
-    """All slabs of one run inside this process (one host thread drives every GPU, or several slabs on one GPU)."""
+    """All slabs of one run inside this process (one host thread drives every GPU, or several slabs on one GPU).  blocks = (d0, d1):
+    the reference's 2-D decomposition instead of phi-slabs, d0 theta-blocks x d1 phi-blocks, in rank order c0 d1 + c1."""
 
-    def __init__(self, params, n_slabs, devices=None):
+    def __init__(self, params, n_slabs, devices=None, blocks=None):
+        if blocks is not None:
+            d0, d1 = blocks
+            n_slabs = d0 * d1
         devices = devices or [0] * n_slabs
-        self.slabs = [Slab(params, k, n_slabs, devices[k]) for k in range(n_slabs)]
+        if blocks is None:
+            self.slabs = [Slab(params, k, n_slabs, devices[k]) for k in range(n_slabs)]
+        else:
+            self.slabs = [Slab(params, device=devices[c0 * d1 + c1], block=(c0, d0, c1, d1)) for c0 in range(d0) for c1 in range(d1)]
         self._arr = (C.c_void_p * n_slabs)(*[s.handle for s in self.slabs])
         check(lib().crd_comm_attach_local(self._arr, n_slabs), "crd_comm_attach_local", self.slabs[0].handle)
         self.grid = self.slabs[0].grid
 
     def upload(self, y):
         for s in self.slabs:
-            s.upload(y[s.js:s.je + 1])
+            s.upload(y[s.js:s.je + 1, s.is_:s.ie + 1])
+
+    def _assemble(self, parts, dtype):
+        out = np.empty((self.grid.ny, self.grid.nx, 2), dtype=dtype)
+        for s, q in zip(self.slabs, parts):
+            out[s.js:s.je + 1, s.is_:s.ie + 1] = q
+        return out
 
     def download(self, dtype=np.float64):
-        return np.concatenate([s.download(dtype) for s in self.slabs], axis=0)
+        return self._assemble([s.download(dtype) for s in self.slabs], dtype)
 
     def f(self, t, y):
-        """ydot = f(t, y) on the whole grid, evaluated slab by slab with halos exchanged between the slabs' vectors."""
+        """ydot = f(t, y) on the whole grid, evaluated block by block with halos exchanged between the blocks' vectors."""
         n = len(self.slabs)
-        parts = [np.ascontiguousarray(y[s.js:s.je + 1], dtype=s.dtype) for s in self.slabs]
+        parts = [np.ascontiguousarray(y[s.js:s.je + 1, s.is_:s.ie + 1], dtype=s.dtype) for s in self.slabs]
         outs = [np.empty_like(q) for q in parts]
         ins = (C.c_void_p * n)(*[q.ctypes.data for q in parts])
         out = (C.c_void_p * n)(*[q.ctypes.data for q in outs])
         check(lib().crd_group_rhs_host(self._arr, n, t, ins, out), "crd_group_rhs_host", self.slabs[0].handle)
-        return np.concatenate(outs, axis=0)
+        return self._assemble(outs, outs[0].dtype)
 
     def step_rk4(self, t0, dt, nsteps):
         check(lib().crd_group_step_rk4(self._arr, len(self.slabs), t0, dt, nsteps), "crd_group_step_rk4", self.slabs[0].handle)

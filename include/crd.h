@@ -129,6 +129,16 @@ int crd_grid_from_params(const crd_params *p, crd_grid *g);
 /* phi-slab extents: SetupDecomp (src/FHNmodel_torus.cpp:750-755) with dims = {1, n_slabs}. */
 int crd_slab_extents(int64_t ny, int slab, int n_slabs, int64_t *js, int64_t *je);
 
+/* The reference's own 2-D (theta x phi) block decomposition: MPI_Dims_create(nprocs, 2, dims) as SetupDecomp
+ * calls it (src/FHNmodel_torus.cpp:724-728: 4 -> {2, 2}, 8 -> {4, 2}, 2 -> {2, 1}), and the extents of block (c0, c1) of a d0 x d1
+ * process grid (:750-753: is = nx c0 / d0, ie = nx (c0 + 1) / d0 - 1, likewise js, je).  The rank of a block is MPI's Cartesian
+ * rank, c0 d1 + c1.  Blocks with d0 > 1 step with the staged kernels (one ghost row / column strip of var0 per stage, the four
+ * strips of the reference's Exchange(), :775-950) in LOCAL groups; the one-launch stepper, the adaptive integrators and the RCCL
+ * transport need phi-slabs (d0 = 1), which is the layout to use on one node -- the block layout exists so that `-np 4` of the
+ * reference's scripts (util/ShellScripts/runFHNmodelTorus.sh:6) can be reproduced file for file. */
+int crd_dims_create(int nprocs, int *d0, int *d1);
+int crd_block_extents(int64_t nx, int64_t ny, int c0, int d0, int c1, int d1, int64_t *is, int64_t *ie, int64_t *js, int64_t *je);
+
 /* Stable state used by the initial conditions and the banner: FHN analytic (src/FHNmodel_torus.cpp:242-244);
  * Goldbeter fixed point, computed natively instead of popen("SolveGoldbeterODE.py")
  * (src/GoldbeterModel_torus.cpp:254-261). */
@@ -146,6 +156,9 @@ int crd_steady_state_as_printed(int model, double beta, int decimals, double *s0
  * src/FHNmodel_torus.cpp:285-354, src/FHNmodel_flat.cpp:280-319, src/GoldbeterModel_torus.cpp:313-414,
  * src/GoldbeterModel_flat.cpp:309-379. */
 int crd_initial_conditions(const crd_run_config *cfg, int64_t js, int64_t je, double *y_aos);
+/* ... of the block [is, ie] x [js, je] (2 (ie-is+1) (je-js+1) values, IDX with nxl = ie-is+1).  The rand() rule draws row by row
+ * through the block from the default seed, as every reference rank does. */
+int crd_initial_conditions_block(const crd_run_config *cfg, int64_t is, int64_t ie, int64_t js, int64_t je, double *y_aos);
 
 /* Largest step the classical RK4 scheme takes stably on this problem: 2.785 / lambda_max (2.785 = the extent of RK4's stability
  * region on the negative real axis), with
@@ -165,6 +178,7 @@ double crd_stable_dt(const crd_params *p);
  * <Model>_<surface>_subdomain.%03i.txt, <Model>_<surface>_<var0>.%03i.txt, <..>_<var1>.%03i.txt in `dir`. */
 typedef struct crd_writer crd_writer;
 int crd_writer_open(const crd_run_config *cfg, const char *dir, int slab, int n_slabs, crd_writer **out);
+int crd_writer_open_block(const crd_run_config *cfg, const char *dir, int rank, int c0, int d0, int c1, int d1, crd_writer **out); /* block (c0, c1) of d0 x d1 */
 int crd_writer_write_row(crd_writer *w, const double *y_aos); /* one output time: nyl*nxl values per file */
 int crd_writer_close(crd_writer *w);
 
@@ -187,6 +201,10 @@ int crd_device_count(void);
 
 /* slab / n_slabs: which phi-slab of the global grid this context owns; device: HIP device ordinal. */
 int crd_create(const crd_params *p, int slab, int n_slabs, int device, crd_ctx **out);
+/* Block (c0, c1) of a d0 x d1 decomposition (crd_create(p, slab, n, ...) = crd_create_block(p, 0, 1, slab, n, ...)); group arrays
+ * (crd_comm_attach_local, crd_group_*) hold the blocks in rank order, c0 d1 + c1. */
+int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int device, crd_ctx **out);
+int crd_get_block(const crd_ctx *ctx, int64_t *is, int64_t *ie, int64_t *js, int64_t *je);
 void crd_destroy(crd_ctx *ctx);
 const char *crd_last_error(const crd_ctx *ctx); /* never NULL; ctx may be NULL (creation errors) */
 

@@ -114,6 +114,30 @@ def test_driver_adaptive_mode(gpu_device, tmp_path):
     assert rel_err(u3, np.stack(frames)[..., 0]) <= 1e-9
 
 
+@pytest.mark.parametrize("decomp", ["2x2", "mpi"])
+def test_driver_writes_the_references_np4_block_layout(gpu_device, tmp_path, decomp):
+    """`crd_run --gpus 4 --decomp 2x2` (or `--decomp mpi`: MPI_Dims_create of the slab count): the four file sets of the
+    reference's `mpirun -np 4` run (util/ShellScripts/runFHNmodelTorus.sh:6) -- subdomain headers with the 2 x 2 extents of
+    SetupDecomp, rows of nyl * nxl values per block -- stitched by the plot script's loader logic and compared with the oracle."""
+    cfg = crd.load_ini(INI, "fhn", "torus")
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--gpus", "4", "--devices", "1", "--decomp", decomp, INI], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "nprocs = 4" in r.stdout and "nxl = 8" in r.stdout and "nyl = 20" in r.stdout
+    for rank, (c0, c1) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
+        hdr = open(tmp_path / ("FHNmodel_torus_subdomain.%03d.txt" % rank)).read().split()
+        assert tuple(int(v) for v in hdr[:6]) == (16, 40) + crd.block_extents(16, 40, c0, 2, c1, 2)
+    want = oracle_outputs(cfg)
+    u, meta = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "u")
+    v, _ = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "v")
+    assert meta["nprocs"] == 4 and u.shape == want[..., 0].shape
+    assert np.array_equal(u[0], want[0, ..., 0]) and rel_err(u, want[..., 0]) <= 1e-9 and rel_err(v, want[..., 1]) <= 1e-9
+    # what the block layout does not do is refused up front
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--gpus", "4", "--decomp", "2x2", "--adaptive", INI], cwd=tmp_path,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 1 and "theta-blocks" in r.stderr
+
+
 def test_driver_stops_when_any_slab_blows_up(gpu_device, tmp_path):
     """Round-2 advice: the blow-up guard must be sticky over the slabs -- a NaN confined to slab 0 of a two-slab run was
     overwritten by slab 1's finite maximum and the driver kept writing NaN frames.  A step six times the stability limit

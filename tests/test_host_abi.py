@@ -332,6 +332,45 @@ int main(void) {
     assert r.returncode == 0 and "ok" in r.stdout, (r.returncode, r.stdout, r.stderr)
 
 
+def test_block_decomposition_follows_setupdecomp(tmp_path):
+    """The reference's 2-D layout: MPI_Dims_create(np, 2) as SetupDecomp calls it
+    (src/FHNmodel_torus.cpp:724-728), block extents (:750-753) against the oracle's restatement of the same lines, the initial
+    conditions of a block = the block of the whole field, and the subdomain header of a block's files."""
+    assert [crd.dims_create(n) for n in (1, 2, 3, 4, 6, 7, 8, 9, 12, 16)] == [(1, 1), (2, 1), (3, 1), (2, 2), (3, 2), (7, 1), (4, 2), (3, 3), (4, 3), (4, 4)]
+    rng = np.random.default_rng(11)
+    for _ in range(60):
+        nx, ny = int(rng.integers(8, 300)), int(rng.integers(8, 300))
+        d0, d1 = int(rng.integers(1, 5)), int(rng.integers(1, 5))
+        op = co.make_problem(co.FHN, co.TORUS, nx, 80.0, 20.0, 0.12, 1.25, ny=ny)
+        cover = np.zeros((ny, nx), dtype=int)
+        for c0 in range(d0):
+            for c1 in range(d1):
+                is_, ie, js, je = crd.block_extents(nx, ny, c0, d0, c1, d1)
+                sub = co.subproblem(op, d0, d1, c0, c1)
+                assert (is_, ie, js, je) == (sub.is_, sub.ie, sub.js, sub.je)
+                cover[js:je + 1, is_:ie + 1] += 1
+        assert np.all(cover == 1)  # the blocks tile the grid
+    with pytest.raises(crd._capi.CrdError):
+        crd.block_extents(10, 10, 2, 2, 0, 1)
+    # initial conditions of a block, all four programs' rules
+    for model, surface, kw in (("fhn", "torus", {}), ("fhn", "flat", {}), ("goldbeter", "torus", dict(wave_inside=1)), ("goldbeter", "flat", {})):
+        p = crd.make_params(model, surface, 37, 80.0, 20.0, 0.12, 1.25 if model == "fhn" else 0.4, ny=50)
+        cfg = crd.run_config(p, wave_length=0.2, wave_width=0.5, **kw)
+        whole = crd.initial_conditions(cfg)
+        for c0, c1 in ((0, 0), (1, 2), (2, 1)):
+            is_, ie, js, je = crd.block_extents(37, 50, c0, 3, c1, 3)
+            assert np.array_equal(crd.initial_conditions(cfg, js, je, is_, ie), whole[js:je + 1, is_:ie + 1])
+    # files of block (1, 0) of 2 x 2 = MPI rank 2: header "nx ny is ie js je xmin xmax tfinal", rows of nyl * nxl values
+    cfg = crd.load_ini(os.path.join(INI, "small_run.ini"), "fhn", "torus")
+    with crd.Writer(cfg, tmp_path, block=(1, 2, 0, 2)) as w:
+        blk = crd.initial_conditions(cfg, 0, 19, 8, 15)
+        w.write_row(blk)
+    hdr = open(tmp_path / "FHNmodel_torus_subdomain.002.txt").read().split()
+    assert [int(v) for v in hdr[:6]] == [16, 40, 8, 15, 0, 19]
+    row = np.loadtxt(tmp_path / "FHNmodel_torus_u.002.txt", ndmin=2)
+    assert row.shape == (1, 20 * 8) and np.array_equal(row[0].reshape(20, 8), blk[..., 0])
+
+
 def test_seeded_sweep_of_host_side_rules_against_the_oracle():
     """300 seeded random parameter sets through the host-only entry points, each against the oracle's restatement: geometry
     scalars (incl. the `(long)(nx * R / r)` truncation and the flat `nx * (long)(L / W)` rule), slab extents that tile the
