@@ -206,3 +206,143 @@ def test_halo_plan_shape():
             assert sends[0][1] == (slab + 1) % world and recvs[0][1] == (slab - 1) % world
     with pytest.raises(crd._capi.CrdError):
         crd.halo_plan(0, 2, 3, 4)
+
+
+class _StandInSlab:
+    """What bench.run needs of crdmodel_amd.Slab, with the planes in numpy and the halos moved by the library's own ring plan
+    over gloo.  NOT a compute path: stepping does nothing but count; this exists so that bench.py's N > 1 control flow runs
+    with real ranks before it ever meets more than one GPU."""
+
+    exposed_ms_by_rank = {}  # rank -> exposed halo wait per exchange the stand-in reports (to exercise the slack decision)
+
+    def __init__(self, crd, dist, params, rank, world, device):
+        self.crd, self.dist, self.params, self.slab, self.n_slabs = crd, dist, params, rank, world
+        self.grid = crd.grid_of(params)
+        self.js, self.je = crd.slab_extents(self.grid.ny, rank, world)
+        self.nx, self.nyl = self.grid.nx, self.je - self.js + 1
+        self.dtype = np.float64 if params.precision == 0 else np.float32
+        self.plane = np.zeros((2, self.nyl + 64, self.nx), dtype=self.dtype)
+        self.ring, self.diag, self.slack, self.steps, self.calls = False, False, 1, 0, []
+
+    def init_rccl(self, ident):
+        assert bytes(ident) == b"\x07" * 128, "the id every rank joins with is rank 0's"
+        self.ring = True
+
+    def set_stepper(self, stepper):
+        self.calls.append(("stepper", stepper))
+
+    def comm_info(self):
+        return ("rccl", self.n_slabs, self.slab) if self.ring else ("self", 1, 0)
+
+    def upload(self, y):
+        assert y.shape == (self.nyl, self.nx, 2)
+        self.plane[0, 32:32 + self.nyl], self.plane[1, 32:32 + self.nyl] = y[..., 0], y[..., 1]
+
+    def halo_exchange(self, depth):
+        for var in (0, 1):
+            view = np.ascontiguousarray(self.plane[var, 32 - depth:32 + self.nyl + depth])
+            _exchange(self.dist, view, self.nyl, depth, self.slab, self.n_slabs, self.crd)
+            self.plane[var, 32 - depth:32 + self.nyl + depth] = view
+
+    def download_rows(self, var, row_begin, row_count):
+        return self.plane[var, 32 + row_begin:32 + row_begin + row_count].copy()
+
+    def dominant_kernel(self):
+        return "crd_rk4_fused_step_kernel"
+
+    def dominant_kernel_rows(self):
+        return self.nyl + 48
+
+    def plan_launches(self):
+        self.calls.append(("plan",))
+
+    def launch_plan(self):
+        return {"autotune": 1, "tuned": 1, "one_round": 0, "xcd_mapping": 2, "rows": self.nyl, "columns_per_lane": 1, "ms_default": 0.06, "ms_chosen": 0.058}
+
+    def step_rk4(self, t0, dt, nsteps, sync=True):
+        self.steps += nsteps
+
+    def step_rk4_timed(self, t0, dt, nsteps):
+        self.steps += nsteps
+        self.last_timed = nsteps
+        return 0.06 * nsteps, 0.055, 1
+
+    def set_diagnostics(self, on):
+        self.diag = bool(on)
+
+    def set_halo_slack(self, sweeps):
+        self.slack = sweeps
+
+    def step_timing(self):
+        n = max(1, self.last_timed // 8)
+        exposed = self.exposed_ms_by_rank.get(self.slab, 0.011) if self.slack == 1 else 0.012
+        return {"ms_total": 0.06 * self.last_timed, "kernel_ms": 0.055, "exposed_halo_ms": exposed * n, "exchange_ms": 0.09 * n, "steps": self.last_timed,
+                "halo_slack": self.slack, "halo_waits": n, "exchanges": n, "agreement_restarts": 0}
+
+    def max_abs(self):
+        return 2.0
+
+    def close(self):
+        self.calls.append(("close",))
+
+
+def _bench_worker(rank, world, port, result_dir, exposed_rank):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import types
+
+    import torch.distributed as dist
+
+    import bench
+    import crdmodel_amd as crd
+
+    slabs = []
+
+    def make_slab(params, r, w, device):
+        slabs.append(_StandInSlab(crd, dist, params, r, w, device))
+        return slabs[-1]
+
+    _StandInSlab.exposed_ms_by_rank = {exposed_rank: 0.08} if exposed_rank >= 0 else {}
+    fake = types.SimpleNamespace(make_params=crd.make_params, stable_dt=crd.stable_dt, run_config=crd.run_config, initial_conditions=crd.initial_conditions,
+                                 rccl_unique_id=lambda: b"\x07" * 128, Slab=make_slab)
+    lines = []
+    args = bench.parse(["--gpus", str(world), "--size", "128", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    try:
+        bench.run(args, fake, world, rank, rank, lambda: None, lines.append)
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+    if rank == 0:
+        assert len(lines) == 1
+        open(os.path.join(result_dir, "line.json"), "w").write(lines[0])
+    else:
+        assert not lines  # rank 0 alone prints
+    assert slabs[0].calls[-1] == ("close",) and slabs[0].slack == (2 if exposed_rank >= 0 else 1)
+    open(os.path.join(result_dir, "ok.%d" % rank), "w").write("ok")
+
+
+@pytest.mark.parametrize("world,exposed_rank", [(2, -1), (3, 2)])
+def test_bench_multi_rank_control_flow(tmp_path, world, exposed_rank):
+    """bench.run -- the function `python bench.py` runs -- with 2 and 3 real processes over gloo and a stand-in for the device
+    context (numpy planes; halos moved by the library's own ring plan): set-up roll call, the 128-byte id from rank 0, the halo
+    self-check against the rows the neighbours really own, the rehearsal that gives the exchange a third sweep of cover when ANY
+    rank reports an exposed wait (rank 2 of 3 does here), the timed region's bracket, the per-rank gather, one JSON line from
+    rank 0 alone with the N > 1 fields.  (What it cannot exercise is RCCL and the kernels: those run on the self-ring in -m gpu.)"""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_bench_worker, args=(world, port, str(tmp_path), exposed_rank), nprocs=world, join=True)
+    assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.%d" % r for r in range(world)]
+    d = json.loads(open(os.path.join(tmp_path, "line.json")).read())
+    assert d["n_gpus"] == world and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong" and d["unit"] == "grid-point-steps/s"
+    assert d["value"] == pytest.approx(128 * 128 * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9) and "cpu_baseline" not in d
+    halo = d["config"]["halo"]
+    assert halo["transport"] == "rccl" and halo["rccl_comm_count"] == world and halo["control_plane"] == "gloo"
+    assert halo["halo_selfcheck"]["ok"] and halo["halo_selfcheck"]["mismatching_values"] == 0
+    if exposed_rank >= 0:
+        assert halo["slack"]["sweeps"] == 2 and halo["slack"]["rehearsal_exposed_halo_ms_max_over_ranks"] == pytest.approx([0.08, 0.012])
+    else:
+        assert halo["slack"]["sweeps"] == 1 and halo["slack"]["rehearsal_exposed_halo_ms_max_over_ranks"] == pytest.approx([0.011])
+    assert [r["rank"] for r in d["per_rank"]] == list(range(world))
+    assert all(r["halo_slack"] == halo["slack"]["sweeps"] and r["exchanges"] == 3 and r["kernel_ms"] == 0.055 for r in d["per_rank"])
+    assert d["roofline"]["kernel"] == "crd_rk4_fused_step_kernel" and d["roofline"]["bound"] == "hbm" and d["config"]["decomposition"] == "phi-slabs x%d" % world
