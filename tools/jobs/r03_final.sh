@@ -48,7 +48,37 @@ CRD_FUSED_REMAP=2 CRD_FUSED_COLS=1 pmc_pair fhn_f64_map2 67108864
 CRD_FUSED_REMAP=1 CRD_FUSED_COLS=2 pmc_pair fhn_f32_16384_map1_cols2 268435456 --size 16384 --precision f32
 CRD_FUSED_REMAP=0 CRD_FUSED_COLS=1 pmc_pair fhn_f32_16384_map0_cols1 268435456 --size 16384 --precision f32
 CRD_FUSED_REMAP=1 CRD_FUSED_COLS=2 CRD_FUSED_ONEROUND=1 pmc_pair goldbeter_f64_4096_oneround_map1_cols2 16777216 --size 4096 --model goldbeter
+CRD_FUSED_REMAP=1 CRD_FUSED_COLS=1 pmc_pair fhn_f64_map1 67108864
+CRD_FUSED_REMAP=1 CRD_FUSED_COLS=1 pmc_pair fhn_f32_8192_map1_cols1 67108864 --precision f32
+CRD_FUSED_REMAP=2 CRD_FUSED_COLS=1 pmc_pair fhn_f32_8192_map2_cols1 67108864 --precision f32
+CRD_FUSED_REMAP=0 CRD_FUSED_COLS=2 pmc_pair fhn_f32_16384_map0_cols2 268435456 --size 16384 --precision f32
+CRD_FUSED_REMAP=2 CRD_FUSED_COLS=2 pmc_pair fhn_f32_16384_map2_cols2 268435456 --size 16384 --precision f32
+CRD_FUSED_REMAP=0 CRD_FUSED_COLS=1 pmc_pair goldbeter_f64_map0 67108864 --model goldbeter
+CRD_FUSED_REMAP=2 CRD_FUSED_COLS=1 pmc_pair goldbeter_f64_map2 67108864 --model goldbeter
+# issue-side counters of the Goldbeter instantiation at 4096^2: one column per lane on the plain plan against two columns on one-round chunks
+for v in "cols1 0 1" "cols2 1 2"; do set -- $v
+  CRD_FUSED_ONEROUND=$2 CRD_FUSED_COLS=$3 CRD_FUSED_REMAP=0 MODEL=goldbeter NX=4096 NY=4096 STEPS=60 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/sq_gb4096_$1 -- python3 $R/tools/slab_run.py > $OUT/pmc/sq_gb4096_$1.log 2>&1
+done
+python3 - <<'PY' > $OUT/pmc/sq_goldbeter_4096.json
+import csv, glob, collections, json, os
+out = {}
+for d in sorted(glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r03/final/pmc/sq_gb4096_*/")):
+    agg = collections.defaultdict(list)
+    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "fused" in r["Kernel_Name"]:
+                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    rec = {k: sum(v) / len(v) for k, v in agg.items()}
+    rec["launches_sampled"] = max((len(v) for v in agg.values()), default=0)
+    if "SQ_INSTS_VALU" in rec:
+        rec["valu_wave_instructions_per_grid_point"] = rec["SQ_INSTS_VALU"] / (4096.0 * 4096.0)
+    out[d.rstrip("/").split("_")[-1]] = rec
+print(json.dumps(out, indent=1))
+PY
+cat $OUT/pmc/sq_goldbeter_4096.json; rm -rf $OUT/pmc/sq_gb4096_cols1 $OUT/pmc/sq_gb4096_cols2
 unset CRD_TUNING
+# the driver's N > 1 launch line with one rank (the launcher's environment, the gloo-free path of the control plane)
+cd $R && python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --staged-steps 0 > $OUT/bench_under_torchrun_n1.json 2> $OUT/bench_under_torchrun_n1.err; tail -c 400 $OUT/bench_under_torchrun_n1.json; cd /tmp
 # markers
 cat > /tmp/marker.ini <<'INI'
 [Parameters]
