@@ -286,7 +286,7 @@ class _StandInSlab:
         self.calls.append(("close",))
 
 
-def _bench_worker(rank, world, port, result_dir, exposed_rank):
+def _bench_worker(rank, world, port, result_dir, exposed_rank, size):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import types
@@ -306,7 +306,7 @@ def _bench_worker(rank, world, port, result_dir, exposed_rank):
     fake = types.SimpleNamespace(make_params=crd.make_params, stable_dt=crd.stable_dt, run_config=crd.run_config, initial_conditions=crd.initial_conditions,
                                  rccl_unique_id=lambda: b"\x07" * 128, Slab=make_slab)
     lines = []
-    args = bench.parse(["--gpus", str(world), "--size", "128", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
+    args = bench.parse(["--gpus", str(world), "--size", str(size), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
     try:
         bench.run(args, fake, world, rank, rank, lambda: None, lines.append)
     finally:
@@ -321,9 +321,9 @@ def _bench_worker(rank, world, port, result_dir, exposed_rank):
     open(os.path.join(result_dir, "ok.%d" % rank), "w").write("ok")
 
 
-@pytest.mark.parametrize("world,exposed_rank", [(2, -1), (3, 2)])
+@pytest.mark.parametrize("world,exposed_rank", [(2, -1), (3, 2), (8, 5)])
 def test_bench_multi_rank_control_flow(tmp_path, world, exposed_rank):
-    """bench.run -- the function `python bench.py` runs -- with 2 and 3 real processes over gloo and a stand-in for the device
+    """bench.run -- the function `python bench.py` runs -- with 2, 3 and 8 real processes over gloo and a stand-in for the device
     context (numpy planes; halos moved by the library's own ring plan): set-up roll call, the 128-byte id from rank 0, the halo
     self-check against the rows the neighbours really own, the rehearsal that gives the exchange a third sweep of cover when ANY
     rank reports an exposed wait (rank 2 of 3 does here), the timed region's bracket, the per-rank gather, one JSON line from
@@ -331,11 +331,12 @@ def test_bench_multi_rank_control_flow(tmp_path, world, exposed_rank):
     import torch.multiprocessing as mp
 
     port = _free_port()
-    mp.spawn(_bench_worker, args=(world, port, str(tmp_path), exposed_rank), nprocs=world, join=True)
+    size = 128 if world < 8 else 512  # a slab of the deep-halo cycle holds at least its 32 ghost rows
+    mp.spawn(_bench_worker, args=(world, port, str(tmp_path), exposed_rank, size), nprocs=world, join=True)
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.%d" % r for r in range(world)]
     d = json.loads(open(os.path.join(tmp_path, "line.json")).read())
     assert d["n_gpus"] == world and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "strong" and d["unit"] == "grid-point-steps/s"
-    assert d["value"] == pytest.approx(128 * 128 * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9) and "cpu_baseline" not in d
+    assert d["value"] == pytest.approx(size * size * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9) and "cpu_baseline" not in d
     halo = d["config"]["halo"]
     assert halo["transport"] == "rccl" and halo["rccl_comm_count"] == world and halo["control_plane"] == "gloo"
     assert halo["halo_selfcheck"]["ok"] and halo["halo_selfcheck"]["mismatching_values"] == 0

@@ -307,6 +307,8 @@ def test_seeded_sweep_of_driver_runs(gpu_device, tmp_path):
         else:
             cmd = [os.path.join(BIN, "crd_run"), "--model", model, "--surface", surface, "--gpus", str(gpus), "--devices", "1", "--quiet",
                    "--stepper", ("auto", "staged")[int(rng.integers(2))]] + (["--binary"] if binary else []) + [str(ini)]
+            if gpus == 2 and not binary:  # cases 1, 3, 6 -- the reference's own layout for two ranks: MPI_Dims_create(2) = 2 theta-blocks x 1
+                cmd = cmd[:-1] + ["--decomp", "mpi", str(ini)]
         r = subprocess.run(cmd, cwd=d, capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (case, cmd, r.stderr)
         cfg = crd.load_ini(ini, model, surface)
