@@ -165,6 +165,7 @@ _SIGNATURES = {
     "crd_trace_range_pop": (None, []),
     "crd_set_autotune": (C.c_int, [_vp, C.c_int]),
     "crd_get_launch_plan": (C.c_int, [_vp, C.POINTER(LaunchPlan)]),
+    "crd_set_launch_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int]),
     "crd_plan_launches": (C.c_int, [_vp]),
     "crd_set_diagnostics": (C.c_int, [_vp, C.c_int]),
     "crd_set_halo_slack": (C.c_int, [_vp, C.c_int]),

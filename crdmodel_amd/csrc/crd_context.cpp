@@ -672,6 +672,20 @@ int crd_set_autotune(crd_ctx *c, int on)
 	return CRD_OK;
 }
 
+int crd_set_launch_plan(crd_ctx *c, int chunk_mode, int xcd_mapping, int columns_per_lane)
+{
+	if (!c) return CRD_EINVAL;
+	if (chunk_mode < 0 || chunk_mode > 2 || xcd_mapping < 0 || xcd_mapping > 2 || columns_per_lane < 1 || columns_per_lane > 2)
+		return fail(c, CRD_EINVAL, "crd_set_launch_plan: chunk mode 0..2, mapping 0..2, columns per lane 1..2");
+	c->plan.tuned = 1;
+	c->plan.one_round = chunk_mode;
+	c->plan.remap = xcd_mapping;
+	c->plan.cols = columns_per_lane;
+	c->plan.rows = c->nyl;  // (launches within a tenth of this height take the plan: the sweeps of a deep-halo cycle do)
+	c->plan.ms_default = c->plan.ms_best = 0.f;
+	return CRD_OK;
+}
+
 int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
 {
 	if (!c || !out) return CRD_EINVAL;

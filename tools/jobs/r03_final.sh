@@ -29,6 +29,10 @@ SIZES=4096,8192 python tools/adaptive_rate.py 2>&1 | grep "n=" > $OUT/adaptive_r
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fused -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats_fused_bench.json 2> $OUT/stats_fused.log
 cp $(find $OUT/stats_fused -name "*kernel_stats.csv" | head -1) $OUT/fused_8192_kernel_stats.csv; head -6 $OUT/fused_8192_kernel_stats.csv
+# ... and with the plan of the first bench run pinned (bench.py --launch-plan): every launch of the kernel is then the plan that is timed
+PLAN=$(python3 -c "import json;p=json.loads(open('$OUT/bench_fused_8192.json').read().strip().splitlines()[-1])['config']['launch_plan'];print('%d,%d,%d'%(p['one_round'],p['xcd_mapping'],p['columns_per_lane']))")
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pinned -- python3 $R/bench.py --no-cpu-baseline --launch-plan $PLAN > $OUT/bench_pinned_plan.json 2> $OUT/stats_pinned.log
+cp $(find $OUT/stats_pinned -name "*kernel_stats.csv" | head -1) $OUT/fused_8192_kernel_stats_pinned_plan.csv; head -4 $OUT/fused_8192_kernel_stats_pinned_plan.csv; rm -rf $OUT/stats_pinned
 rocprofv3 --kernel-trace --output-format csv -d $OUT/ring_trace -- python3 $R/tools/ring_trace.py > $OUT/ring_trace.log 2>&1
 cd $R && python tools/trace_timeline.py $(find $OUT/ring_trace -name "*kernel_trace.csv" | head -1) 40 > $OUT/ring_cycle_timeline_8192x1024.txt; tail -14 $OUT/ring_cycle_timeline_8192x1024.txt
 rm -rf $OUT/stats_fused $OUT/ring_trace
