@@ -672,15 +672,17 @@ int crd_set_autotune(crd_ctx *c, int on)
 	return CRD_OK;
 }
 
-int crd_set_launch_plan(crd_ctx *c, int chunk_mode, int xcd_mapping, int columns_per_lane)
+int crd_set_launch_plan(crd_ctx *c, int chunk_mode, int xcd_mapping, int columns_per_lane, int nontemporal_stores)
 {
 	if (!c) return CRD_EINVAL;
-	if (chunk_mode < 0 || chunk_mode > 2 || xcd_mapping < 0 || xcd_mapping > 2 || columns_per_lane < 1 || columns_per_lane > 2)
-		return fail(c, CRD_EINVAL, "crd_set_launch_plan: chunk mode 0..2, mapping 0..2, columns per lane 1..2");
+	if (chunk_mode < 0 || chunk_mode > 2 || xcd_mapping < 0 || xcd_mapping > 2 || columns_per_lane < 1 || columns_per_lane > 2 || nontemporal_stores < 0 ||
+	    nontemporal_stores > 1)
+		return fail(c, CRD_EINVAL, "crd_set_launch_plan: chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1");
 	c->plan.tuned = 1;
 	c->plan.one_round = chunk_mode;
 	c->plan.remap = xcd_mapping;
 	c->plan.cols = columns_per_lane;
+	c->plan.nt = nontemporal_stores;
 	c->plan.rows = c->nyl;  // (launches within a tenth of this height take the plan: the sweeps of a deep-halo cycle do)
 	c->plan.ms_default = c->plan.ms_best = 0.f;
 	return CRD_OK;
@@ -695,6 +697,8 @@ int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
 	out->xcd_mapping = c->plan.remap;
 	out->rows = c->plan.rows;
 	out->columns_per_lane = c->plan.cols;
+	out->nontemporal_stores = c->plan.nt;
+	out->reserved = 0;
 	out->ms_default = c->plan.ms_default;
 	out->ms_chosen = c->plan.ms_best;
 	return CRD_OK;

@@ -142,6 +142,16 @@ __device__ __forceinline__ float uniform(float x) { return __int_as_float(__buil
 
 // (non-temporal row loads measured 19 % slower, fp64 and fp32 alike: the apron rows and columns two items share come from cache)
 #define CRD_ROW_LOAD(p) (*(p))
+// The new state is written once and not read again by this launch.  NT = true gives its stores the non-temporal hint
+// (`global_store ... nt`): the lines do not stay in L2 at the expense of the apron rows and columns neighbouring items share --
+// a launch-plan choice (FusedPlan::nt), measured like the others: -6.5 % on 8192^2 fp64 under the plain mapping, -8 % at 4096^2,
+// +1 % on some two-column plans (profiles/r03/nt_stores.txt).
+template <bool NT, typename T>
+__device__ __forceinline__ void row_store(T *p, T v)
+{
+	if constexpr (NT) __builtin_nontemporal_store(v, p);
+	else *p = v;
+}
 
 template <typename Real>
 struct FusedArgs {
@@ -192,10 +202,12 @@ struct FusedArgs {
 // side), rows are read and written with one 8-byte (fp32) or 16-byte (fp64) access per lane, a stage needs ONE DPP move per
 // direction for two columns, and the fp32 arithmetic is the packed instructions (v_pk_fma_f32 ...).  Needs an even nx (the
 // pair must not straddle the periodic seam); results are the one-column kernel's bit for bit.
-template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS>
+// NT = true: the new state is stored with the non-temporal hint (row_store above).
+template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false>
 __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
 	static_assert(COLS == 1 || (COLS == 2 && EMBED == 0), "the embedded pairs run one column per lane");
+	static_assert(!NT || EMBED == 0, "the embedded pairs store plainly");
 	using V = typename LaneValue<Real, COLS>::type;
 	constexpr bool ZONN = EMBED == 2;
 	constexpr int APRON = EMBED != 0 ? kApron + 1 : kApron;
@@ -415,8 +427,8 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 			// Without the fifth stage rows j0 <= c < j1 are exactly iterations 8 .. niter-1; with it (one more apron row each side)
 			// the first and the last iteration of the range fall outside.
 			if ((EMBED == 0 || (c >= j0 && c < j1)) && lane_stores) {
-				*at_lane_as<V>(out_row_u, ob) = nu;
-				*at_lane_as<V>(out_row_v, ob) = nv;
+				row_store<NT>(at_lane_as<V>(out_row_u, ob), nu);
+				row_store<NT>(at_lane_as<V>(out_row_v, ob), nv);
 			}
 			if (EMBED == 1) {
 				U4[S4] = nu;
@@ -531,7 +543,7 @@ int resident_wavefronts()
 		int dev = 0, cus = 256, blocks_per_cu = 4;
 		hipDeviceProp_t prop;
 		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0, COLS>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0, COLS, false>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
 		    blocks_per_cu < 1)
 			blocks_per_cu = 4;
 		(void)hipGetLastError();
@@ -580,11 +592,15 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols)  // 0: 32 
 // Third dimension (round 3): columns per lane.  Two columns per lane halve the DPP moves and the apron share of a strip (8 of 128
 // columns instead of 8 of 64) and, in fp32, use the packed arithmetic; they also halve the wavefronts in flight for the same
 // bytes.  Which wins is again a matter of the kernel (fp32 / Goldbeter are issue-bound, FHN fp64 is not) and of the device.
+// Fourth dimension (round 3, late): non-temporal stores of the new state (row_store).  They keep L2 for what items share; which
+// mapping is fastest changes with them (the plain mapping gains most), so they are timed in combination.
 struct PlanCandidate {
-	int one_round, remap, cols;  // one_round: the chunk mode -- 0 = 32 rows, 1 = stretched to one round, 2 = 64 rows
+	int one_round, remap, cols, nt;  // one_round: the chunk mode -- 0 = 32 rows, 1 = stretched to one round, 2 = 64 rows
 };
-constexpr PlanCandidate kPlanCandidates[] = {{0, 0, 1}, {0, 1, 1}, {0, 2, 1}, {1, 0, 1}, {1, 1, 1}, {2, 0, 1}, {2, 1, 1},
-                                             {0, 0, 2}, {0, 1, 2}, {0, 2, 2}, {1, 0, 2}, {1, 1, 2}, {2, 0, 2}};
+constexpr PlanCandidate kPlanCandidates[] = {{0, 0, 1, 0}, {0, 1, 1, 0}, {0, 2, 1, 0}, {1, 0, 1, 0}, {1, 1, 1, 0}, {2, 0, 1, 0}, {2, 1, 1, 0},
+                                             {0, 0, 2, 0}, {0, 1, 2, 0}, {0, 2, 2, 0}, {1, 0, 2, 0}, {1, 1, 2, 0}, {2, 0, 2, 0},
+                                             {0, 0, 1, 1}, {0, 1, 1, 1}, {0, 2, 1, 1}, {1, 0, 1, 1}, {1, 1, 1, 1}, {2, 0, 1, 1},
+                                             {0, 0, 2, 1}, {0, 1, 2, 1}, {0, 2, 2, 1}, {1, 0, 2, 1}, {1, 1, 2, 1}, {2, 0, 2, 1}};
 
 template <typename Real, int MODEL>
 hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, int js, int ny,
@@ -640,7 +656,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const dim3 block(kLanes * sw);
 
 	int cols = cols_default;
-	auto configure = [&](int one_round, int remap, int want_cols) {
+	bool nt = false;
+	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0) {
+		nt = want_nt != 0 && !c.embed;
+		if (const char *e = tuning_knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0 && !c.embed;  // tuning knob
 		cols = (want_cols == 2 && cols2_ok) ? 2 : 1;
 		if (const char *e = tuning_knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;  // tuning knob
 		const int valid = cols * kLanes - 2 * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
@@ -721,13 +740,22 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				crd_rk4_fused_step_kernel<Real, MODEL, false, 1, 1><<<a.nblocks, block, 0, st>>>(s, a);
 			}
 			crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
-		} else if (cols == 2) {
-			if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 0, 2><<<a.nblocks, block, 0, st>>>(s, a);
-			else crd_rk4_fused_step_kernel<Real, MODEL, false, 0, 2><<<a.nblocks, block, 0, st>>>(s, a);
-		} else if (absorb) {
-			crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 0, 1><<<a.nblocks, block, 0, st>>>(s, a);
 		} else {
-			crd_rk4_fused_step_kernel<Real, MODEL, false, 0, 1><<<a.nblocks, block, 0, st>>>(s, a);
+			// plain step: absorbing rows x columns per lane x store hint, all compile-time
+			auto with = [&](auto absorb_c, auto cols_c, auto nt_c) {
+				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value>
+				    <<<a.nblocks, block, 0, st>>>(s, a);
+			};
+			auto with_cols = [&](auto absorb_c, auto nt_c) {
+				if (cols == 2) with(absorb_c, std::integral_constant<int, 2>{}, nt_c);
+				else with(absorb_c, std::integral_constant<int, 1>{}, nt_c);
+			};
+			auto with_nt = [&](auto absorb_c) {
+				if (nt) with_cols(absorb_c, std::true_type{});
+				else with_cols(absorb_c, std::false_type{});
+			};
+			if (absorb) with_nt(std::true_type{});
+			else with_nt(std::false_type{});
 		}
 		return launch_status();
 	};
@@ -743,6 +771,30 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		hipError_t err = hipDeviceSynchronize();
 		if (err == hipSuccess) err = hipEventCreate(&e0);
 		if (err == hipSuccess) err = hipEventCreate(&e1);
+		// What a candidate is timed on: with a scratch plane set, launches that step yout -> scratch -> yout -> ... (each reads what
+		// its predecessor wrote, as consecutive steps do); without, repetitions of y0 -> yout.  The difference matters on slabs
+		// small enough for the memory-side cache: an input that is never overwritten stays there, and a plan that keeps its output
+		// out of the caches (non-temporal stores) then looks better than it steps.
+		const bool pingpong = c.tune_scratch.u != nullptr && c.tune_scratch.v != nullptr;
+		auto set_io = [&](const Planes &in, const Planes &out) {
+			a.in_u = row0<Real>(in.u, d.nx);
+			a.in_v = row0<Real>(in.v, d.nx);
+			a.out_u = row0<Real>(out.u, d.nx);
+			a.out_v = row0<Real>(out.v, d.nx);
+		};
+		int flip = 0;
+		auto fire_timed = [&]() -> hipError_t {
+			if (pingpong) {
+				if (flip) set_io(c.tune_scratch, c.yout);
+				else set_io(c.yout, c.tune_scratch);
+				flip ^= 1;
+			}
+			return fire();
+		};
+		if (pingpong && err == hipSuccess) {
+			configure(0, 0, cols_default, 0);
+			err = fire();  // yout holds a state to step on from
+		}
 		// Candidates are timed round-robin, kRounds times, and each keeps its best round: a device's clock drifts while the
 		// measurement runs (a Goldbeter launch sequence lost 15 % over five candidates timed one after the other), and a
 		// candidate must not win or lose by its place in the queue.
@@ -752,20 +804,21 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		int reps = 3;
 		for (int k = 0; k < kCandidates; k++) {
 			t_best[k] = 0.f;
-			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols);
+			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt);
 			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.r_chunk[0] == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols));  // (same as a 32-row plan)
 			if (live[k] && kPlanCandidates[k].remap != a.remap) live[k] = false;  // (the mapping fell back to dispatch order)
 			if (live[k] && kPlanCandidates[k].cols != cols) live[k] = false;      // (two columns per lane not possible here, or pinned by a knob)
+			if (live[k] && (kPlanCandidates[k].nt != 0) != nt) live[k] = false;   // (pinned by a knob)
 		}
 		for (int round = 0; round < kRounds && err == hipSuccess; round++)
 			for (int k = 0; err == hipSuccess && k < kCandidates; k++) {
 				if (!live[k]) continue;
-				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols);
+				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt);
 				float ms = 0.f;
 				for (int pass = 0; pass < 2 && err == hipSuccess; pass++) {
-					err = fire();  // warm-up of this variant
+					err = fire_timed();  // warm-up of this variant
 					if (err == hipSuccess) err = hipEventRecord(e0, st);
-					for (int r = 0; err == hipSuccess && r < reps; r++) err = fire();
+					for (int r = 0; err == hipSuccess && r < reps; r++) err = fire_timed();
 					if (err == hipSuccess) err = hipEventRecord(e1, st);
 					if (err == hipSuccess) err = hipEventSynchronize(e1);
 					if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
@@ -775,30 +828,69 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (err != hipSuccess) break;
 				ms /= (float)reps;
 				if (std::getenv("CRD_AUTOTUNE_VERBOSE"))
-					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane: %.4f ms per launch (%d launches timed)\n",
-					             d.nx, rows, round, kPlanCandidates[k].one_round, a.r_chunk[0], a.remap, cols, ms, reps);
+					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores: %.4f ms per launch (%d launches timed)\n",
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.r_chunk[0], a.remap, cols, nt ? "non-temporal" : "plain", ms, reps);
 				if (t_best[k] == 0.f || ms < t_best[k]) t_best[k] = ms;
 			}
+		// Final: with two dozen candidates a few per cent apart, the fastest of the short bursts above is as often the luckiest as
+		// the best, and a burst runs at clocks a sustained run does not keep.  The plain plan and the three fastest candidates are
+		// therefore timed again, ~16 ms each and twice round, and the final alone decides between them.
+		constexpr int kFinalists = 4, kFinalRounds = 2;
+		int finalist[kFinalists] = {0, -1, -1, -1};
+		for (int f = 1; f < kFinalists; f++)
+			for (int k = 1; k < kCandidates; k++) {
+				if (!live[k] || t_best[k] <= 0.f || k == finalist[1] || k == finalist[2]) continue;
+				if (finalist[f] < 0 || t_best[k] < t_best[finalist[f]]) finalist[f] = k;
+			}
+		float t_final[kFinalists] = {0.f, 0.f, 0.f, 0.f};
+		for (int round = 0; round < kFinalRounds && err == hipSuccess; round++)
+			for (int f = 0; err == hipSuccess && f < kFinalists; f++) {
+				const int k = finalist[f];
+				if (k < 0 || t_best[k] <= 0.f) continue;
+				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt);
+				const int reps2 = (int)(16.0f / t_best[k]) + 1 < 400 ? (int)(16.0f / t_best[k]) + 1 : 400;
+				float ms = 0.f;
+				err = fire_timed();
+				if (err == hipSuccess) err = hipEventRecord(e0, st);
+				for (int r = 0; err == hipSuccess && r < reps2; r++) err = fire_timed();
+				if (err == hipSuccess) err = hipEventRecord(e1, st);
+				if (err == hipSuccess) err = hipEventSynchronize(e1);
+				if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+				if (err != hipSuccess) break;
+				ms /= (float)reps2;
+				if (std::getenv("CRD_AUTOTUNE_VERBOSE"))
+					std::fprintf(stderr, "libcrd autotune: %d x %d rows, final %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores: %.4f ms per launch (%d launches timed)\n",
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.r_chunk[0], a.remap, cols, nt ? "non-temporal" : "plain", ms, reps2);
+				if (t_final[f] == 0.f || ms < t_final[f]) t_final[f] = ms;
+			}
 		int best_k = 0;
-		for (int k = 1; k < kCandidates; k++)
-			if (live[k] && t_best[k] > 0.f && t_best[k] < t_best[best_k]) best_k = k;
-		const float base = t_best[0], best = t_best[best_k];
+		float base = t_best[0], best = t_best[0];
+		if (t_final[0] > 0.f) {
+			base = best = t_final[0];
+			for (int f = 1; f < kFinalists; f++)
+				if (finalist[f] >= 0 && t_final[f] > 0.f && t_final[f] < best) {
+					best = t_final[f];
+					best_k = finalist[f];
+				}
+		}
 		if (e0) (void)hipEventDestroy(e0);
 		if (e1) (void)hipEventDestroy(e1);
+		set_io(c.y0, c.yout);  // (the launch this call was made for follows below)
 		if (err != hipSuccess) return err;
 		if (best > 0.985f * base) best_k = 0;  // a candidate has to beat the plain plan by more than timing noise
 		plan->tuned = 1;
 		plan->one_round = kPlanCandidates[best_k].one_round;
 		plan->remap = kPlanCandidates[best_k].remap;
 		plan->cols = kPlanCandidates[best_k].cols;
+		plan->nt = kPlanCandidates[best_k].nt;
 		plan->rows = rows;
 		plan->ms_default = base;
 		plan->ms_best = best_k ? best : base;
 	}
 	const bool use_plan = plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows;
 	// (launches the plan was not measured on -- edge bands, short ranges -- still take its columns per lane: that choice is about
-	// the kernel's arithmetic, not about the launch's shape)
-	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default);
+	// the kernel's arithmetic, not about the launch's shape; the store hint stays with the launches it was measured on)
+	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default, use_plan ? plan->nt : 0);
 	return fire();
 }
 

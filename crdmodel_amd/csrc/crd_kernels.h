@@ -66,6 +66,7 @@ struct FusedPlan {
 	int tuned = 0;
 	int one_round = 0, remap = 0;
 	int cols = 1;                          // grid columns per lane (1 or 2)
+	int nt = 0;                            // the new state stored with the non-temporal hint
 	int rows = 0;                          // height of the launch the plan was measured on
 	float ms_default = 0.f, ms_best = 0.f;  // measured launch times of the plain plan and of the chosen one
 };
@@ -82,6 +83,10 @@ struct FusedCall {
 	int err_capacity = 0;
 	double *err_sum = nullptr;       // device: the sum, written by a follow-up reduction on the same stream
 	FusedPlan *plan = nullptr;       // launch plan of the context (nullptr: plain plan)
+	// A third plane set the plan measurement may overwrite: candidates are then timed stepping yout -> scratch -> yout ..., every
+	// launch reading what the previous one wrote as real stepping does, instead of repeating y0 -> yout (whose input, never
+	// overwritten, stays in the 256 MB memory-side cache on slabs that fit: a one-GPU share of an 8-GPU run does).
+	Planes tune_scratch{nullptr, nullptr};
 	// The last step of a multi-slab exchange cycle as ONE launch (rows [0, nyl), no second range): the two edge bands of band_rows
 	// rows go first, and when they are in memory the kernel itself writes flag_value to *flag (signal memory a stream waits on
 	// with hipStreamWaitValue64); flag_counter: a zero-initialised device word the band blocks count themselves in with.

@@ -360,6 +360,8 @@ FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int ds
 	call.y0 = c->planes(src);
 	call.yout = c->planes(dst);
 	call.plan = const_cast<FusedPlan *>(&c->plan);
+	// (ACC is the staged stepper's accumulator and a temporary of arkHin / the Hermite output: free whenever a one-launch step runs)
+	if (src != crd_ctx::ACC && dst != crd_ctx::ACC) call.tune_scratch = c->planes(crd_ctx::ACC);
 	return call;
 }
 

@@ -310,9 +310,9 @@ class Slab:
     def set_autotune(self, on):
         self._check(lib().crd_set_autotune(self._h, 1 if on else 0), "crd_set_autotune")
 
-    def set_launch_plan(self, chunk_mode, xcd_mapping, columns_per_lane):
+    def set_launch_plan(self, chunk_mode, xcd_mapping, columns_per_lane, nontemporal_stores=0):
         """Pin the launch plan of the fixed-step kernel (crd_set_launch_plan) instead of having it measured."""
-        self._check(lib().crd_set_launch_plan(self._h, chunk_mode, xcd_mapping, columns_per_lane), "crd_set_launch_plan")
+        self._check(lib().crd_set_launch_plan(self._h, chunk_mode, xcd_mapping, columns_per_lane, nontemporal_stores), "crd_set_launch_plan")
 
     def plan_launches(self):
         """Measure the fused step kernel's launch plan now (state not advanced) rather than inside the first step_rk4."""

@@ -401,7 +401,8 @@ int crd_dominant_kernel_rows(const crd_ctx *ctx, int64_t *rows);
 const char *crd_dominant_kernel_name(const crd_ctx *ctx);
 
 /* Launch plan of the one-launch step kernel.  How a slab is cut into work items (32-row chunks, or chunks stretched so that
- * every workgroup is resident at once) and how the items are dealt to the 8 XCDs is measured on the device at hand, on the
+ * every workgroup is resident at once), how the items are dealt to the 8 XCDs, how many columns a lane steps and how the new
+ * state is stored is measured on the device at hand, on the
  * context's first full-size step (a handful of extra launches of that step; every plan computes bit-identical results), unless
  * autotuning is off (crd_set_autotune(ctx, 0) or CRD_AUTOTUNE=0 in the environment: always the plain plan).  No reference
  * counterpart: a property of this implementation. */
@@ -413,16 +414,19 @@ typedef struct crd_launch_plan {
 	int32_t rows;         /* height of the launch it was measured on */
 	int32_t columns_per_lane; /* 1: a wavefront steps a strip of 64 columns (56 valid); 2: 128 columns (120 valid), two per lane -- packed
 	                           * arithmetic in fp32 */
+	int32_t nontemporal_stores; /* 1: the new state is written with the non-temporal hint (it is not read again by the launch, and
+	                             * does not displace from L2 what neighbouring work items share) */
+	int32_t reserved;
 	double ms_default, ms_chosen; /* measured launch times: plain plan, chosen plan */
 } crd_launch_plan;
 int crd_set_autotune(crd_ctx *ctx, int on);
 int crd_get_launch_plan(const crd_ctx *ctx, crd_launch_plan *out);
-/* Use THIS plan (chunk mode 0..2, mapping 0..2, columns per lane 1..2) for the fixed-step kernel instead of measuring one -- a plan
+/* Use THIS plan (chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1) for the fixed-step kernel instead of measuring one -- a plan
  * read back from an earlier context of the same shape on the same device (the measurement costs ~90 ms per context at 8192^2), or
  * a profiling run in which every launch of the kernel should be the plan a previous run chose (`bench.py --launch-plan`).  Where
  * a choice cannot be honoured (two columns per lane on an odd nx, mapping 2 on a launch too short for it) the launch falls back as
  * it would for a measured plan.  crd_get_launch_plan then reports tuned = 1 with both times 0.  CRD_EINVAL outside the ranges. */
-int crd_set_launch_plan(crd_ctx *ctx, int chunk_mode, int xcd_mapping, int columns_per_lane);
+int crd_set_launch_plan(crd_ctx *ctx, int chunk_mode, int xcd_mapping, int columns_per_lane, int nontemporal_stores);
 /* Measure the plan NOW (a step of the resident state into scratch planes, discarded; the state is not advanced) instead of
  * inside the first crd_step_rk4 -- for callers that time their first steps; also creates the events crd_step_rk4_timed uses.  The
  * measurement is skipped when a plan exists or autotuning is off. */

@@ -21,7 +21,7 @@ unset CRD_AUTOTUNE_VERBOSE
 for f in $OUT/*.json $OUT/configs/*.json; do python - "$f" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1]); r=d['roofline']; s=d.get('staged')
-print(sys.argv[1].split('/')[-1], 'ms/step %.4f value %.3e kernel_ms %.4f frac %.3f plan %s' % (d['ms_per_step'], d['value'], r['kernel_ms'], r['frac'], {k:d['config']['launch_plan'][k] for k in ('tuned','one_round','xcd_mapping','columns_per_lane')}), ('staged.frac %.3f' % s['frac']) if s else '')
+print(sys.argv[1].split('/')[-1], 'ms/step %.4f value %.3e kernel_ms %.4f frac %.3f plan %s' % (d['ms_per_step'], d['value'], r['kernel_ms'], r['frac'], {k:d['config']['launch_plan'].get(k) for k in ('tuned','one_round','xcd_mapping','columns_per_lane','nontemporal_stores')}), ('staged.frac %.3f' % s['frac']) if s else '')
 PY
 done
 NYS=1024,2048,4096 VARIANTS=self,rccl:0 python tools/ring_overhead.py 2>&1 | grep "ny=" > $OUT/ring_overhead.txt; cat $OUT/ring_overhead.txt
@@ -30,57 +30,13 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_fused -- python3 $R/bench.py --no-cpu-baseline > $OUT/stats_fused_bench.json 2> $OUT/stats_fused.log
 cp $(find $OUT/stats_fused -name "*kernel_stats.csv" | head -1) $OUT/fused_8192_kernel_stats.csv; head -6 $OUT/fused_8192_kernel_stats.csv
 # ... and with the plan of the first bench run pinned (bench.py --launch-plan): every launch of the kernel is then the plan that is timed
-PLAN=$(python3 -c "import json;p=json.loads(open('$OUT/bench_fused_8192.json').read().strip().splitlines()[-1])['config']['launch_plan'];print('%d,%d,%d'%(p['one_round'],p['xcd_mapping'],p['columns_per_lane']))")
+PLAN=$(python3 -c "import json;p=json.loads(open('$OUT/bench_fused_8192.json').read().strip().splitlines()[-1])['config']['launch_plan'];print('%d,%d,%d,%d'%(p['one_round'],p['xcd_mapping'],p['columns_per_lane'],p.get('nontemporal_stores',0)))")
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_pinned -- python3 $R/bench.py --no-cpu-baseline --launch-plan $PLAN > $OUT/bench_pinned_plan.json 2> $OUT/stats_pinned.log
 cp $(find $OUT/stats_pinned -name "*kernel_stats.csv" | head -1) $OUT/fused_8192_kernel_stats_pinned_plan.csv; head -4 $OUT/fused_8192_kernel_stats_pinned_plan.csv; rm -rf $OUT/stats_pinned
 rocprofv3 --kernel-trace --output-format csv -d $OUT/ring_trace -- python3 $R/tools/ring_trace.py > $OUT/ring_trace.log 2>&1
 cd $R && python tools/trace_timeline.py $(find $OUT/ring_trace -name "*kernel_trace.csv" | head -1) 40 > $OUT/ring_cycle_timeline_8192x1024.txt; tail -14 $OUT/ring_cycle_timeline_8192x1024.txt
 rm -rf $OUT/stats_fused $OUT/ring_trace
-# PMC traffic of the plans in use (separate --pmc passes, as the guide prescribes; plan pinned with the tuning knobs)
-cd /tmp
-export CRD_TUNING=1
-pmc_pair() { # name, points, bench args...
-  local name=$1 pts=$2; shift 2
-  for ctr in FETCH_SIZE WRITE_SIZE; do
-    rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc/${name}_$ctr -- python3 $R/bench.py --steps 30 --warmup 5 --no-cpu-baseline --staged-steps 0 "$@" > $OUT/pmc/${name}_$ctr.log 2>&1
-  done
-  python3 $R/tools/pmc_summary.py $(find $OUT/pmc/${name}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $OUT/pmc/${name}_WRITE_SIZE -name "*counter_collection.csv" | head -1) --points $pts --match fused > $OUT/pmc/traffic_$name.json
-  cat $OUT/pmc/traffic_$name.json; rm -rf $OUT/pmc/${name}_FETCH_SIZE $OUT/pmc/${name}_WRITE_SIZE
-}
-CRD_FUSED_REMAP=0 CRD_FUSED_COLS=1 pmc_pair fhn_f64_map0 67108864
-CRD_FUSED_REMAP=2 CRD_FUSED_COLS=1 pmc_pair fhn_f64_map2 67108864
-CRD_FUSED_REMAP=1 CRD_FUSED_COLS=2 pmc_pair fhn_f32_16384_map1_cols2 268435456 --size 16384 --precision f32
-CRD_FUSED_REMAP=0 CRD_FUSED_COLS=1 pmc_pair fhn_f32_16384_map0_cols1 268435456 --size 16384 --precision f32
-CRD_FUSED_REMAP=1 CRD_FUSED_COLS=2 CRD_FUSED_ONEROUND=1 pmc_pair goldbeter_f64_4096_oneround_map1_cols2 16777216 --size 4096 --model goldbeter
-CRD_FUSED_REMAP=1 CRD_FUSED_COLS=1 pmc_pair fhn_f64_map1 67108864
-CRD_FUSED_REMAP=1 CRD_FUSED_COLS=1 pmc_pair fhn_f32_8192_map1_cols1 67108864 --precision f32
-CRD_FUSED_REMAP=2 CRD_FUSED_COLS=1 pmc_pair fhn_f32_8192_map2_cols1 67108864 --precision f32
-CRD_FUSED_REMAP=0 CRD_FUSED_COLS=2 pmc_pair fhn_f32_16384_map0_cols2 268435456 --size 16384 --precision f32
-CRD_FUSED_REMAP=2 CRD_FUSED_COLS=2 pmc_pair fhn_f32_16384_map2_cols2 268435456 --size 16384 --precision f32
-CRD_FUSED_REMAP=0 CRD_FUSED_COLS=1 pmc_pair goldbeter_f64_map0 67108864 --model goldbeter
-CRD_FUSED_REMAP=2 CRD_FUSED_COLS=1 pmc_pair goldbeter_f64_map2 67108864 --model goldbeter
-# issue-side counters of the Goldbeter instantiation at 4096^2: one column per lane on the plain plan against two columns on one-round chunks
-for v in "cols1 0 1" "cols2 1 2"; do set -- $v
-  CRD_FUSED_ONEROUND=$2 CRD_FUSED_COLS=$3 CRD_FUSED_REMAP=0 MODEL=goldbeter NX=4096 NY=4096 STEPS=60 rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc/sq_gb4096_$1 -- python3 $R/tools/slab_run.py > $OUT/pmc/sq_gb4096_$1.log 2>&1
-done
-python3 - <<'PY' > $OUT/pmc/sq_goldbeter_4096.json
-import csv, glob, collections, json, os
-out = {}
-for d in sorted(glob.glob(os.environ["GRAFT_REPO_ROOT"] + "/gpurun_out/r03/final/pmc/sq_gb4096_*/")):
-    agg = collections.defaultdict(list)
-    for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
-        for r in csv.DictReader(open(f)):
-            if "fused" in r["Kernel_Name"]:
-                agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
-    rec = {k: sum(v) / len(v) for k, v in agg.items()}
-    rec["launches_sampled"] = max((len(v) for v in agg.values()), default=0)
-    if "SQ_INSTS_VALU" in rec:
-        rec["valu_wave_instructions_per_grid_point"] = rec["SQ_INSTS_VALU"] / (4096.0 * 4096.0)
-    out[d.rstrip("/").split("_")[-1]] = rec
-print(json.dumps(out, indent=1))
-PY
-cat $OUT/pmc/sq_goldbeter_4096.json; rm -rf $OUT/pmc/sq_gb4096_cols1 $OUT/pmc/sq_gb4096_cols2
-unset CRD_TUNING
+# (PMC traffic of the plans in use: tools/jobs/r03_final_pmc.sh, a call of its own)
 # the driver's N > 1 launch line with one rank (the launcher's environment, the gloo-free path of the control plane)
 cd $R && python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --staged-steps 0 > $OUT/bench_under_torchrun_n1.json 2> $OUT/bench_under_torchrun_n1.err; tail -c 400 $OUT/bench_under_torchrun_n1.json; cd /tmp
 # markers

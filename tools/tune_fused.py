@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Interleaved A/B timing of fused-stepper variants in ONE process (guide rule: N variants x M rounds, report median/min).
 Variants are environment knobs the launch code reads on every launch: CRD_FUSED_CHUNK, CRD_FUSED_REMAP (0 / 1 / 2), CRD_FUSED_STRIPS, CRD_FUSED_ONEROUND,
-CRD_FUSED_COLS (1 / 2 columns per lane)."""
+CRD_FUSED_COLS (1 / 2 columns per lane), CRD_FUSED_NT (non-temporal stores of the new state)."""
 import os
 import statistics
 import sys
@@ -29,7 +29,7 @@ slab.step_rk4(0.0, dt, 50)
 res = {v: [] for v in variants}
 for r in range(rounds):
     for v in variants:
-        for k in ("CRD_FUSED_CHUNK", "CRD_FUSED_REMAP", "CRD_FUSED_STRIPS", "CRD_FUSED_ONEROUND", "CRD_FUSED_COLS"):
+        for k in ("CRD_FUSED_CHUNK", "CRD_FUSED_REMAP", "CRD_FUSED_STRIPS", "CRD_FUSED_ONEROUND", "CRD_FUSED_COLS", "CRD_FUSED_NT"):
             os.environ.pop(k, None)
         for kv in v.split(","):
             key, val = kv.split("=")
@@ -43,6 +43,8 @@ for r in range(rounds):
                 os.environ["CRD_FUSED_REMAP"] = val
             if key == "cols":
                 os.environ["CRD_FUSED_COLS"] = val
+            if key == "nt":
+                os.environ["CRD_FUSED_NT"] = val
         ms, kms, _ = slab.step_rk4_timed(0.0, dt, steps)
         res[v].append(ms / steps)
 for v in variants:
