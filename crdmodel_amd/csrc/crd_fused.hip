@@ -345,7 +345,9 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	auto iteration = [&](int m, auto kk, auto guarded) {
 		constexpr int K = decltype(kk)::value;
 		constexpr bool GUARDED = decltype(guarded)::value;
+#ifndef CRD_NO_LOCKSTEP  // (an experiment switch: -DCRD_NO_LOCKSTEP lets a block's wavefronts drift)
 		__builtin_amdgcn_s_barrier();  // lockstep; uniform over the block: its wavefronts share the chunk, hence niter
+#endif
 		// slots of rows p, p-1, ... p-6 (with M = 4, row p-4 shares its slot with row p)
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M;
 		constexpr int S5 = (K + 2 * M - 5) % M, S6 = (K + 2 * M - 6) % M;

@@ -11,7 +11,7 @@ pmc_pair() { # name, points, bench args...
   for ctr in FETCH_SIZE WRITE_SIZE; do
     rocprofv3 --pmc $ctr --output-format csv -d $OUT/pmc/${name}_$ctr -- python3 $R/bench.py --steps 30 --warmup 5 --preheat-ms 0 --no-cpu-baseline --staged-steps 0 "$@" > $OUT/pmc/${name}_$ctr.log 2>&1
   done
-  python3 $R/tools/pmc_summary.py $(find $OUT/pmc/${name}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $OUT/pmc/${name}_WRITE_SIZE -name "*counter_collection.csv" | head -1) --points $pts --match fused > $OUT/pmc/traffic_$name.json
+  python3 $R/tools/pmc_summary.py $(find $OUT/pmc/${name}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $OUT/pmc/${name}_WRITE_SIZE -name "*counter_collection.csv" | head -1) --points $pts --match ${MATCH:-fused} > $OUT/pmc/traffic_$name.json
   cat $OUT/pmc/traffic_$name.json; rm -rf $OUT/pmc/${name}_FETCH_SIZE $OUT/pmc/${name}_WRITE_SIZE
 }
 if [ "${PMC_SET:-all}" != "nt" ]; then   # PMC_SET=nt: only the plans with non-temporal stores (the others were recorded by an earlier call)
@@ -61,3 +61,5 @@ pmc_pair fhn_f32_16384_map0_cols2_nt 268435456 --size 16384 --precision f32 --la
 pmc_pair fhn_f32_16384_map1_cols2_nt 268435456 --size 16384 --precision f32 --launch-plan 0,1,2,1
 pmc_pair fhn_f32_16384_map0_cols1_nt 268435456 --size 16384 --precision f32 --launch-plan 0,0,1,1
 pmc_pair fhn_f32_16384_map1_cols1_nt 268435456 --size 16384 --precision f32 --launch-plan 0,1,1,1
+# the staged stepper's kernels (non-temporal stores of their results on slabs of 32 MiB per plane and more)
+MATCH=stage_kernel pmc_pair staged_fhn_f64_8192 67108864 --stepper staged
