@@ -14,7 +14,7 @@ pmc_pair() { # name, points, bench args...
   python3 $R/tools/pmc_summary.py $(find $OUT/pmc/${name}_FETCH_SIZE -name "*counter_collection.csv" | head -1) $(find $OUT/pmc/${name}_WRITE_SIZE -name "*counter_collection.csv" | head -1) --points $pts --match ${MATCH:-fused} > $OUT/pmc/traffic_$name.json
   cat $OUT/pmc/traffic_$name.json; rm -rf $OUT/pmc/${name}_FETCH_SIZE $OUT/pmc/${name}_WRITE_SIZE
 }
-if [ "${PMC_SET:-all}" != "nt" ]; then   # PMC_SET=nt: only the plans with non-temporal stores (the others were recorded by an earlier call)
+if [ "${PMC_SET:-all}" = "all" ]; then   # PMC_SET=nt: only the plans with non-temporal stores (the others were recorded by an earlier call)
 CRD_FUSED_REMAP=0 CRD_FUSED_COLS=1 pmc_pair fhn_f64_map0 67108864
 CRD_FUSED_REMAP=2 CRD_FUSED_COLS=1 pmc_pair fhn_f64_map2 67108864
 CRD_FUSED_REMAP=1 CRD_FUSED_COLS=2 pmc_pair fhn_f32_16384_map1_cols2 268435456 --size 16384 --precision f32
@@ -50,6 +50,7 @@ PY
 cat $OUT/pmc/sq_goldbeter_4096.json; rm -rf $OUT/pmc/sq_gb4096_cols1 $OUT/pmc/sq_gb4096_cols2
 fi
 unset CRD_TUNING CRD_FUSED_REMAP CRD_FUSED_COLS CRD_FUSED_ONEROUND
+if [ "${PMC_SET:-all}" != "staged" ]; then
 # plans with non-temporal stores of the new state (late round 3), pinned through the API
 pmc_pair fhn_f64_map0_nt 67108864 --launch-plan 0,0,1,1
 pmc_pair fhn_f64_map1_nt 67108864 --launch-plan 0,1,1,1
@@ -61,5 +62,6 @@ pmc_pair fhn_f32_16384_map0_cols2_nt 268435456 --size 16384 --precision f32 --la
 pmc_pair fhn_f32_16384_map1_cols2_nt 268435456 --size 16384 --precision f32 --launch-plan 0,1,2,1
 pmc_pair fhn_f32_16384_map0_cols1_nt 268435456 --size 16384 --precision f32 --launch-plan 0,0,1,1
 pmc_pair fhn_f32_16384_map1_cols1_nt 268435456 --size 16384 --precision f32 --launch-plan 0,1,1,1
+fi
 # the staged stepper's kernels (non-temporal stores of their results on slabs of 32 MiB per plane and more)
 MATCH=stage_kernel pmc_pair staged_fhn_f64_8192 67108864 --stepper staged
