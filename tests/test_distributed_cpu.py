@@ -257,7 +257,7 @@ class _StandInSlab:
         self.calls.append(("plan",))
 
     def launch_plan(self):
-        return {"autotune": 1, "tuned": 1, "one_round": 0, "xcd_mapping": 2, "rows": self.nyl, "columns_per_lane": 1, "ms_default": 0.06, "ms_chosen": 0.058}
+        return {"autotune": 1, "tuned": 1, "one_round": 0, "xcd_mapping": 2, "rows": self.nyl, "columns_per_lane": 1, "nontemporal_stores": 0, "ms_default": 0.06, "ms_chosen": 0.058}
 
     def step_rk4(self, t0, dt, nsteps, sync=True):
         self.steps += nsteps

@@ -39,6 +39,7 @@ for ny in [int(v) for v in os.environ.get("NYS", "1024,2048,4096").split(",")]:
     for v in variants:
         med = statistics.median(ts[v])
         plan = slabs[v].launch_plan()
-        print("ny=%d %-7s %.2f us/step (min %.2f)  %.3e pt-steps/s  plan: chunk mode %d, mapping %d, %d col/lane" % (
-            ny, v, med * 1e3, min(ts[v]) * 1e3, nx * ny / (med * 1e-3), plan["one_round"], plan["xcd_mapping"], plan["columns_per_lane"]), flush=True)
+        print("ny=%d %-7s %.2f us/step (min %.2f)  %.3e pt-steps/s  plan: chunk mode %d, mapping %d, %d col/lane, %s stores" % (
+            ny, v, med * 1e3, min(ts[v]) * 1e3, nx * ny / (med * 1e-3), plan["one_round"], plan["xcd_mapping"], plan["columns_per_lane"],
+            "non-temporal" if plan["nontemporal_stores"] else "plain"), flush=True)
         slabs[v].close()
