@@ -207,7 +207,6 @@ template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = 
 __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
 	static_assert(COLS == 1 || (COLS == 2 && EMBED == 0), "the embedded pairs run one column per lane");
-	static_assert(!NT || EMBED == 0, "the embedded pairs store plainly");
 	using V = typename LaneValue<Real, COLS>::type;
 	constexpr bool ZONN = EMBED == 2;
 	constexpr int APRON = EMBED != 0 ? kApron + 1 : kApron;
@@ -660,8 +659,8 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	int cols = cols_default;
 	bool nt = false;
 	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0) {
-		nt = want_nt != 0 && !c.embed;
-		if (const char *e = tuning_knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0 && !c.embed;  // tuning knob
+		nt = want_nt != 0;
+		if (const char *e = tuning_knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0;  // tuning knob
 		cols = (want_cols == 2 && cols2_ok) ? 2 : 1;
 		if (const char *e = tuning_knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;  // tuning knob
 		const int valid = cols * kLanes - 2 * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
@@ -733,14 +732,20 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	auto fire = [&]() -> hipError_t {
 		if (c.embed) {
 			if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
-			if (c.embed == 2) {
-				if (absorb) crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 2, 1><<<a.nblocks, block, 0, st>>>(s, a);
-				else crd_rk4_fused_step_kernel<Real, MODEL, false, 2, 1><<<a.nblocks, block, 0, st>>>(s, a);
-			} else if (absorb) {
-				crd_rk4_fused_step_kernel<Real, MODEL, kCanAbsorb, 1, 1><<<a.nblocks, block, 0, st>>>(s, a);
-			} else {
-				crd_rk4_fused_step_kernel<Real, MODEL, false, 1, 1><<<a.nblocks, block, 0, st>>>(s, a);
-			}
+			auto with = [&](auto absorb_c, auto embed_c, auto nt_c) {
+				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, decltype(embed_c)::value, 1, decltype(nt_c)::value>
+				    <<<a.nblocks, block, 0, st>>>(s, a);
+			};
+			auto with_embed = [&](auto absorb_c, auto nt_c) {
+				if (c.embed == 2) with(absorb_c, std::integral_constant<int, 2>{}, nt_c);
+				else with(absorb_c, std::integral_constant<int, 1>{}, nt_c);
+			};
+			auto with_nt = [&](auto absorb_c) {
+				if (nt) with_embed(absorb_c, std::true_type{});
+				else with_embed(absorb_c, std::false_type{});
+			};
+			if (absorb) with_nt(std::true_type{});
+			else with_nt(std::false_type{});
 			crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
 		} else {
 			// plain step: absorbing rows x columns per lane x store hint, all compile-time
