@@ -422,7 +422,7 @@ typedef struct crd_launch_plan {
 int crd_set_autotune(crd_ctx *ctx, int on);
 int crd_get_launch_plan(const crd_ctx *ctx, crd_launch_plan *out);
 /* Use THIS plan (chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1) for the fixed-step kernel instead of measuring one -- a plan
- * read back from an earlier context of the same shape on the same device (the measurement costs ~90 ms per context at 8192^2), or
+ * read back from an earlier context of the same shape on the same device (the measurement costs ~0.45 s per context at 8192^2), or
  * a profiling run in which every launch of the kernel should be the plan a previous run chose (`bench.py --launch-plan`).  Where
  * a choice cannot be honoured (two columns per lane on an odd nx, mapping 2 on a launch too short for it) the launch falls back as
  * it would for a measured plan.  crd_get_launch_plan then reports tuned = 1 with both times 0.  CRD_EINVAL outside the ranges. */

@@ -336,3 +336,46 @@ def test_seeded_sweep_of_driver_runs(gpu_device, tmp_path):
         if binary:
             run = post.load_run(str(d), model, surface, include_all_vars=bool(all_vars))
             assert np.array_equal(run.fields[names[0]], got0)
+
+
+@pytest.mark.gpu
+def test_bench_line_end_to_end(gpu_device):
+    """`python bench.py` as the driver runs it (small grid, few steps): exactly one JSON line on stdout with the contract's keys,
+    internally consistent (value = points x steps / time, roofline.frac = achieved / peak <= 1, kernel time <= step time), the
+    pre-heat reported; then the same through the RCCL self-ring with a pinned launch plan (per_rank diagnostics, halo self-check),
+    and the staged stepper alone."""
+    import json
+    import sys
+
+    def run(*extra):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--size", "1024", "--steps", "8", "--warmup", "2", "--preheat-ms", "20"] + list(extra),
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+        assert len(lines) == 1, r.stdout[-2000:]
+        return json.loads(lines[0])
+
+    d = run("--cpu-rows", "128", "--cpu-steps", "4", "--staged-steps", "4")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config",
+                "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert (d["n_gpus"], d["steps"], d["warmup"], d["unit"], d["dtype"], d["higher_is_better"], d["vs_baseline"]) == (1, 8, 2, "grid-point-steps/s", "f64", True, None)
+    assert d["value"] == pytest.approx(1024 * 1024 * 8 / (d["ms_per_step"] * 8e-3), rel=1e-9) and d["config"]["workload"].startswith("fhn_torus_1024x1024")
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "crd_rk4_fused_step_kernel"
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.0 < r["frac"] <= 1.0 and 0.0 < r["kernel_ms"] <= 1.5 * d["ms_per_step"]
+    assert r["algorithmic_bytes_per_launch"] == 32 * 1024 * 1024 and r["launches_per_step"] == 1
+    assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
+    assert d["config"]["preheat"]["steps"] >= 8 and d["staged"]["kernel"].startswith("crd_rk4_stage_kernel") and 0.0 < d["staged"]["frac"] <= 1.0
+    assert d["config"]["launch_plan"]["tuned"] == 1  # 1024^2 = 1 Mi points: the smallest launch the library measures a plan for
+
+    d = run("--no-cpu-baseline", "--staged-steps", "0", "--force-rccl", "--launch-plan", "0,1,2,1")
+    lp = d["config"]["launch_plan"]
+    assert lp["pinned"] and (lp["one_round"], lp["xcd_mapping"], lp["columns_per_lane"], lp["nontemporal_stores"]) == (0, 1, 2, 1) and "cpu_baseline" not in d
+    halo = d["config"]["halo"]
+    assert halo["transport"] == "rccl" and halo["rccl_comm_count"] == 1 and halo["halo_selfcheck"]["ok"] and halo["slack"]["sweeps"] in (1, 2)
+    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["exchanges"] == 3 and d["per_rank"][0]["rows"] == 1024
+
+    d = run("--no-cpu-baseline", "--stepper", "staged")
+    assert d["roofline"]["kernel"].startswith("crd_rk4_stage_kernel") and d["roofline"]["launches_per_step"] == 2 and "staged" not in d  # (stages 2 and 3 are the launches of the dominant kernel)
+    assert d["roofline"]["algorithmic_bytes_per_launch"] == 80 * 1024 * 1024
