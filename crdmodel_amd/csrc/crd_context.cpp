@@ -206,6 +206,7 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	CREATE_TRY(hipMalloc(&c->edge_lo, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc(&c->edge_hi, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc((void **)&c->scalar_dev, sizeof(double)));
+	CREATE_TRY(hipHostMalloc((void **)&c->scalar_host, 8 * sizeof(double), hipHostMallocPortable | hipHostMallocMapped));
 	if (d0 > 1) {  // theta-blocks: ghost / edge column strips of var0, per stage-input plane and one pair for the AoS RHS
 		const size_t strip = (size_t)c->nyl * c->real_size;
 		for (int side = 0; side < 2; side++) {
@@ -263,6 +264,7 @@ void crd_destroy(crd_ctx *c)
 	if (c->band) (void)hipStreamSynchronize(c->band);
 	if (c->nccl && g_rccl.handle) (void)g_rccl.CommDestroy(c->nccl);
 	for (void *q : c->plane_allocs) (void)hipFree(q);
+	if (c->scalar_host) (void)hipHostFree(c->scalar_host);
 	for (void *q : {c->cA, c->cP, c->brow, c->stage_in, c->stage_out, c->ghost_lo, c->ghost_hi, c->edge_lo, c->edge_hi, (void *)c->scalar_dev,
 	                (void *)c->err_partials, c->ghost_col[0], c->ghost_col[1], c->edge_col[0], c->edge_col[1]})
 		if (q) (void)hipFree(q);
@@ -708,9 +710,11 @@ int crd_state_max_abs(crd_ctx *c, double *out)
 {
 	if (!c || !out) return CRD_EINVAL;
 	if (int rc = set_device(c)) return rc;
-	HIP_TRY(c, launch_max_abs(c->p.precision, c->plane[crd_ctx::Y][0], c->nx, c->nyl, c->scalar_dev, c->compute));
-	HIP_TRY(c, hipMemcpyAsync(out, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
+	double *sink = c->scalar_sink();
+	HIP_TRY(c, launch_max_abs(c->p.precision, c->plane[crd_ctx::Y][0], c->nx, c->nyl, sink, c->compute));
+	if (sink != c->scalar_host) HIP_TRY(c, hipMemcpyAsync(c->scalar_host, sink, sizeof(double), hipMemcpyDeviceToHost, c->compute));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));
+	*out = c->scalar_host[0];
 	return CRD_OK;
 }
 

@@ -126,6 +126,10 @@ struct crd_ctx {
 		return group[(size_t)(((c0 + dtheta + d0) % d0) * d1 + (c1 + dphi + d1) % d1)];
 	}
 	double *scalar_dev = nullptr;
+	double *scalar_host = nullptr;  // page-locked, device-visible host memory
+	// Where a reduction kernel leaves its scalar for the host: straight in host memory (no copy, one synchronisation) unless the
+	// scalar still has to be reduced over the ranks of an RCCL run on the device.
+	double *scalar_sink() const { return (scalar_host && halo != CRD_HALO_RCCL) ? scalar_host : scalar_dev; }
 	double *err_partials = nullptr;  // adaptive stepping: per-item error sums (lazy)
 	int err_capacity = 0;
 

@@ -626,14 +626,22 @@ static int rhs_on_planes(crd_ctx *const *cs, int n, double t, int src, int dst)
 // the maximum, identical on every rank (RCCL: ncclAllReduce; LOCAL groups: added / compared on the host in slab order).
 static int collect_scalar(crd_ctx *const *cs, int n, bool take_max, double *out)
 {
+	// The producers wrote to scalar_sink(): host memory, or -- RCCL runs -- device memory that is reduced over the ranks first and
+	// copied to the page-locked buffer (a copy to pageable memory goes through the runtime's staging buffer: ~10 us per attempt of an
+	// error-controlled run on a small grid).  Every slab's work is enqueued before the first one is waited for.
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = cs[k];
+		if (c->scalar_sink() == c->scalar_host) continue;
+		if (int rc = set_device(c)) return rc;
+		if (c->halo == CRD_HALO_RCCL) NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev, c->scalar_dev, 1, ncclDouble, take_max ? ncclMax : ncclSum, c->nccl, c->compute));
+		HIP_TRY(c, hipMemcpyAsync(c->scalar_host, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
+	}
 	double acc = 0.0;
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
-		if (c->halo == CRD_HALO_RCCL) NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev, c->scalar_dev, 1, ncclDouble, take_max ? ncclMax : ncclSum, c->nccl, c->compute));
-		double part = 0.0;
-		HIP_TRY(c, hipMemcpyAsync(&part, c->scalar_dev, sizeof(double), hipMemcpyDeviceToHost, c->compute));
 		HIP_TRY(c, hipStreamSynchronize(c->compute));
+		const double part = c->scalar_host[0];
 		if (take_max) acc = (part > acc || part != part) ? part : acc;
 		else acc += part;
 	}
@@ -682,7 +690,7 @@ static int arkode_initial_step(crd_ctx *const *cs, int n, double t0, double tout
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
-		HIP_TRY(c, launch_hin_bound(c->p.precision, c->planes(cur), c->planes(crd_ctx::SB), c->nx, c->nyl, o.rtol, o.atol, c->scalar_dev, c->compute));
+		HIP_TRY(c, launch_hin_bound(c->p.precision, c->planes(cur), c->planes(crd_ctx::SB), c->nx, c->nyl, o.rtol, o.atol, c->scalar_sink(), c->compute));
 	}
 	double hub_inv = 0.0;
 	if (int rc = collect_scalar(cs, n, true, &hub_inv)) return rc;
@@ -706,7 +714,7 @@ static int arkode_initial_step(crd_ctx *const *cs, int n, double t0, double tout
 			crd_ctx *c = cs[k];
 			if (int rc = set_device(c)) return rc;
 			HIP_TRY(c, launch_ydd_sumsq(c->p.precision, c->planes(cur), c->planes(crd_ctx::SB), c->planes(crd_ctx::ACC), hg, o.rtol, o.atol, c->nx, c->nyl, c->err_partials,
-			                            c->scalar_dev, c->compute));
+			                            c->scalar_sink(), c->compute));
 		}
 		double sum = 0.0;
 		if (int rc = collect_scalar(cs, n, false, &sum)) return rc;
@@ -847,7 +855,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			call.atol = o.atol;
 			call.err_partials = c->err_partials;
 			call.err_capacity = c->err_capacity;
-			call.err_sum = c->scalar_dev;
+			call.err_sum = c->scalar_sink();
 			if (multi) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
 			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
 		}
