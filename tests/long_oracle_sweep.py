@@ -6,7 +6,9 @@ Every tenth case is large enough (> 1 Mi points) for the launch plan to be measu
 (mapping, columns per lane, non-temporal stores) meets the oracle too.  Prints the worst relative error per precision; exits 1
 past the test suite's bars (1e-9 fp64, 2e-4 fp32).
 
-    SWEEP_SECONDS=300 SWEEP_SEED=1 python3 tools/oracle_sweep.py
+    SWEEP_SECONDS=300 SWEEP_SEED=1 python3 tests/long_oracle_sweep.py
+
+(Kept under tests/ -- not collected by pytest -- because only tests may use the oracle.)
 """
 import os
 import sys
@@ -17,7 +19,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import crdmodel_amd as crd  # noqa: E402
-from oracle import crd_oracle as co  # noqa: E402  (this tool IS a test: oracle use is what it is for)
+from oracle import crd_oracle as co  # noqa: E402
 
 budget = float(os.environ.get("SWEEP_SECONDS", "300"))
 rng = np.random.default_rng(int(os.environ.get("SWEEP_SEED", "1")))
