@@ -231,6 +231,7 @@ def test_header_is_plain_c_and_links_from_c(tmp_path):
 
     src = tmp_path / "abi.c"
     src.write_text(r'''
+#include <stddef.h>
 #include <stdio.h>
 #include <string.h>
 #include "crd.h"
@@ -247,6 +248,9 @@ int main(void) {
 	if (crd_adaptive_defaults(&ao) != CRD_OK || ao.rtol != 1e-5) return 6;
 	if (!(crd_stable_dt(&p) > 0.0)) return 7;
 	printf("%s %ld\n", crd_status_string(CRD_EPARSE), (long)sizeof(crd_run_config));
+	printf("layout %ld %ld %ld %ld %ld %ld %ld %ld %ld %ld\n", (long)sizeof(crd_params), (long)sizeof(crd_grid), (long)sizeof(crd_adaptive_options),
+	       (long)sizeof(crd_adaptive_stats), (long)sizeof(crd_launch_plan), (long)sizeof(crd_step_timing), (long)offsetof(crd_launch_plan, nontemporal_stores),
+	       (long)offsetof(crd_launch_plan, ms_default), (long)offsetof(crd_step_timing, halo_waits), (long)offsetof(crd_adaptive_options, method));
 	return 0;
 }
 ''')
@@ -256,8 +260,12 @@ int main(void) {
                     "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"], check=True)
     r = subprocess.run([str(exe)], capture_output=True, text=True)
     assert r.returncode == 0, (r.returncode, r.stderr)
-    assert r.stdout.split()[:3] == ["ini", "parse", "error"]
-    assert int(r.stdout.split()[-1]) == C.sizeof(crd._capi.RunConfig)  # the ctypes mirror has the C layout
+    assert r.stdout.splitlines()[0].split()[:3] == ["ini", "parse", "error"]
+    assert int(r.stdout.splitlines()[0].split()[-1]) == C.sizeof(crd._capi.RunConfig)  # the ctypes mirror has the C layout
+    k = crd._capi
+    layout = [int(v) for v in r.stdout.splitlines()[1].split()[1:]]
+    assert layout == [C.sizeof(k.Params), C.sizeof(k.Grid), C.sizeof(k.AdaptiveOptions), C.sizeof(k.AdaptiveStats), C.sizeof(k.LaunchPlan), C.sizeof(k.StepTiming),
+                      k.LaunchPlan.nontemporal_stores.offset, k.LaunchPlan.ms_default.offset, k.StepTiming.halo_waits.offset, k.AdaptiveOptions.method.offset]
 
 
 def test_arkrhsfn_shim_compiles_as_c(tmp_path):
