@@ -169,6 +169,18 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	if (const char *e = std::getenv("CRD_BAND_STREAM")) c->bands_on_own_stream = std::atoi(e) != 0;
 	if (const char *e = std::getenv("CRD_HALO_SLACK")) c->halo_slack = std::atoi(e) == 2 ? 2 : 1;
 	if (const char *e = std::getenv("CRD_AUTOTUNE")) c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = std::atoi(e) != 0;
+	// CRD_LAUNCH_PLAN=mode,mapping,columns,nt: what crd_set_launch_plan does, for a program one cannot change (crd_run under a profiler)
+	if (const char *e = std::getenv("CRD_LAUNCH_PLAN")) {
+		int m = -1, k = -1, cols = -1, nt = 0;
+		if (std::sscanf(e, "%d,%d,%d,%d", &m, &k, &cols, &nt) >= 3 && m >= 0 && m <= 2 && k >= 0 && k <= 2 && cols >= 1 && cols <= 2 && nt >= 0 && nt <= 1) {
+			c->plan.tuned = 1;
+			c->plan.one_round = m;
+			c->plan.remap = k;
+			c->plan.cols = cols;
+			c->plan.nt = nt;
+			c->plan.rows = (int)(c->je - c->js + 1);
+		}
+	}
 
 	int ndev = 0;
 	if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return bail(fail(c, CRD_EHIP, "no HIP device available (libcrd has no CPU fallback)"));
