@@ -25,7 +25,7 @@ budget = float(os.environ.get("SWEEP_SECONDS", "300"))
 rng = np.random.default_rng(int(os.environ.get("SWEEP_SEED", "1")))
 bars = {"f64": 1e-9, "f32": 2e-4}
 worst = {"f64": (0.0, None), "f32": (0.0, None)}
-t_start, case, plans = time.time(), 0, {}
+t_start, case, plans, rings = time.time(), 0, {}, 0
 
 
 def rel(a, b):
@@ -68,6 +68,9 @@ while time.time() - t_start < budget:
     tag = (case, model, surface, nx, ny, precision, vary, jd, t_b > 0, n_slabs, stepper)
     if n_slabs == 1:
         with crd.Slab(p) as slab:
+            if big and rng.integers(2):
+                slab.init_rccl(crd.rccl_unique_id())  # the same slab as a world-size-1 RCCL ring: deep-halo cycle, exchanges to self
+                rings += 1
             slab.set_stepper(stepper)
             slab.upload(y0)
             slab.step_rk4(0.0, dt, nsteps)
@@ -91,5 +94,6 @@ while time.time() - t_start < budget:
     case += 1
     if case % 50 == 0:
         print("%d cases, %.0f s: worst fp64 %.2e, worst fp32 %.2e; measured plans met: %s" % (case, time.time() - t_start, worst["f64"][0], worst["f32"][0], sorted(plans.items())), flush=True)
+print("(%d of the large cases stepped through the RCCL self-ring)" % rings)
 print("done: %d cases in %.0f s; worst fp64 %.3e %r; worst fp32 %.3e %r; measured plans (mode, mapping, columns, nt) -> cases: %s"
       % (case, time.time() - t_start, worst["f64"][0], worst["f64"][1], worst["f32"][0], worst["f32"][1], sorted(plans.items())))
