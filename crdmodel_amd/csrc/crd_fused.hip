@@ -536,6 +536,18 @@ const char *tuning_knob(const char *name) { return tuning_enabled() ? std::geten
 // 58.4 us with 32-row chunks and 60.5 with 16; the edge-band launches of a multi-slab step end up with 8-row chunks).
 // `one_round` (a launch-plan choice, see FusedPlan): a launch that needs more than one round of resident blocks but would
 // fit into one with chunks of up to 96 rows gets those longer chunks -- no tail round on an almost idle chip.
+int device_cus()
+{
+	static int cus = 0;  // compute units of a device of this node (the GPUs of a node are alike)
+	if (cus == 0) {
+		int dev = 0;
+		hipDeviceProp_t prop;
+		cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+		(void)hipGetLastError();
+	}
+	return cus;
+}
+
 template <typename Real, int MODEL, int COLS>
 int resident_wavefronts()
 {
@@ -566,6 +578,10 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols)  // 0: 32 
 	const int slots = resident_wavefronts<Real, MODEL>(cols);
 	int chunk = 32;
 	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
+	// Tiny launches: where even 8-row chunks make fewer blocks than half the CUs, 4-row chunks put twice as many CUs to work (256^2:
+	// 7.3 -> 6.4 us per step; the reference's 100 x 400 Goldbeter grid: 8.2 -> 6.5).  With more blocks than that the extra apron rows
+	// cost more than they bring (512^2: 8.9 -> 9.8 us, 400 x 1600: 11.1 -> 12.9; the edge bands of a ring share: no change).
+	if (chunk == 8 && (long)((nstrips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + 7) / 8) < device_cus() / 2) chunk = 4;
 	if (const char *e = tuning_knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
 	if (chunk_mode == 2 && chunk == 32 && (long)nstrips * ((rows + 63) / 64) >= 2L * slots) chunk = 64;  // fewer apron rows recomputed: pays where fp64 issue binds (Goldbeter)
 	if (one_round) {
