@@ -924,8 +924,9 @@ bool fused_step_supported(int, const SlabDesc &d) { return d.nyl >= 2 * kStepHal
 int fused_max_items(const SlabDesc &d)
 {
 	// upper bound on the work items of any launch on this slab: the narrowest strips, the shortest chunks the heuristic uses
+	// (4 rows: launches that leave most CUs idle, fused_chunk_rows)
 	const int strips = (d.nx + (kValid - 2) - 1) / (kValid - 2);
-	return strips * ((d.nyl + 2 * kGhost + 7) / 8 + 2);
+	return strips * ((d.nyl + 2 * kGhost + 3) / 4 + 2);
 }
 
 const char *fused_kernel_name(int, int) { return "crd_rk4_fused_step_kernel"; }
