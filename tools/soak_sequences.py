@@ -3,7 +3,7 @@
 stepping calls of random length, uploads in between, stepper switches, halo slack, diagnostics, timed calls, launch planning,
 short error-controlled integrations -- applied to a single slab, to a LOCAL group of 2-4 slabs (one or several issuing threads)
 and to the world-size-1 RCCL ring, on one GPU.  After every operation the three states must agree: bit for bit after
-fixed-step operations, to 1e-9 after an error-controlled one with the same accepted / rejected counts and last step size and to 1e-5 (its
+fixed-step operations, to 1e-9 after an error-controlled one with the same accepted / rejected counts, last and smallest step size and internal time, and to 1e-5 (its
 tolerance) otherwise (the slabs' error norms are summed in another order; the states are then re-synchronised).  Runs episodes until SOAK_SECONDS are over; any disagreement prints the seed and the operations so
 far and ends with status 1.
 
@@ -122,7 +122,8 @@ while time.time() - t_start < budget:
                 # Same step sequence: same state to rounding.  The slabs' error norms are summed in another order, and where the
                 # controller sits at a limit a last-bit difference in one norm can change a later step size: the sequences then
                 # differ (counted below), and so do the states -- within the integrator's own tolerance.
-                same = len({(st["accepted"], st["rejected"]) for st in stats}) == 1 and all(abs(st["h_last"] - stats[0]["h_last"]) <= 1e-9 * stats[0]["h_last"] for st in stats)
+                same = len({(st["accepted"], st["rejected"]) for st in stats}) == 1 and all(
+                    abs(st[key] - stats[0][key]) <= 1e-9 * abs(stats[0][key]) for st in stats for key in ("h_last", "h_min", "t_internal"))
                 n_diverged += 0 if same else 1
                 upload_all(compare(False, log[-1], 1e-9 if same else 1e-5))  # carry on from one common state
             n_ops += 1
