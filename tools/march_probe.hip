@@ -87,8 +87,20 @@ __global__ void __launch_bounds__(256) march(const double *__restrict__ in_u, co
 				V a, b;
 				set(a, acc);
 				set(b, acc * 0.25);
+#ifdef NT  // (-DNT: the output with the non-temporal hint, as the step kernel's `row_store<true>`)
+				if constexpr (W == 1) {
+					__builtin_nontemporal_store(a, reinterpret_cast<V *>(out_u + (size_t)r * nx + oc));
+					__builtin_nontemporal_store(b, reinterpret_cast<V *>(out_v + (size_t)r * nx + oc));
+				} else {
+					typedef double native2 __attribute__((ext_vector_type(2)));
+					const native2 aa = {a.x, a.y}, bb = {b.x, b.y};
+					__builtin_nontemporal_store(aa, reinterpret_cast<native2 *>(out_u + (size_t)r * nx + oc));
+					__builtin_nontemporal_store(bb, reinterpret_cast<native2 *>(out_v + (size_t)r * nx + oc));
+				}
+#else
 				*reinterpret_cast<V *>(out_u + (size_t)r * nx + oc) = a;
 				*reinterpret_cast<V *>(out_v + (size_t)r * nx + oc) = b;
+#endif
 			}
 		}
 	}
