@@ -21,6 +21,10 @@ __global__ void __launch_bounds__(256) calib_copy8(const double *__restrict__ a,
 {
 	for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) b[q] = a[q];
 }
+__global__ void __launch_bounds__(256) calib_copy8_nt(const double *__restrict__ a, double *__restrict__ b, size_t n)  // stores with the non-temporal hint
+{
+	for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) __builtin_nontemporal_store(a[q], b + q);
+}
 __global__ void __launch_bounds__(256) calib_copy16(const double2 *__restrict__ a, double2 *__restrict__ b, size_t n)
 {
 	for (size_t q = (size_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (size_t)gridDim.x * 256) b[q] = a[q];
@@ -53,6 +57,8 @@ int main()
 		std::printf("write8  %zu B  %.3f ms  %.0f GB/s\n", bytes, ms, bytes / ms / 1e6);
 		CK(hipEventRecord(e0)); calib_copy8<<<grid, 256>>>(a, b, n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
 		std::printf("copy8   %zu B  %.3f ms  %.0f GB/s (read+write)\n", 2 * bytes, ms, 2 * bytes / ms / 1e6);
+		CK(hipEventRecord(e0)); calib_copy8_nt<<<grid, 256>>>(a, b, n); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
+		std::printf("copy8nt %zu B  %.3f ms  %.0f GB/s (read+write, non-temporal stores)\n", 2 * bytes, ms, 2 * bytes / ms / 1e6);
 		CK(hipEventRecord(e0)); calib_copy16<<<grid, 256>>>((const double2 *)a, (double2 *)b, n / 2); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
 		std::printf("copy16  %zu B  %.3f ms  %.0f GB/s (read+write)\n", 2 * bytes, ms, 2 * bytes / ms / 1e6);
 		CK(hipEventRecord(e0)); calib_read4<<<grid, 256>>>((const float *)a, n * 2, (float *)b); CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1)); CK(hipEventElapsedTime(&ms, e0, e1));
