@@ -65,8 +65,13 @@ __device__ __forceinline__ void sweep_item(const Args &a, int step, int chunk, i
 			const double lu = __shfl(wu[4], lane - 4, 64), ru = __shfl(wu[4], lane + 4, 64);
 			const double lv = __shfl(wv[4], lane - 4, 64), rv = __shfl(wv[4], lane + 4, 64);
 			if (m >= 2 * kApron && r < j1 && stores) {
+#ifdef NT  // (-DNT: non-temporal stores -- is the producers' release still a write-back of a whole dirty L2 then?)
+				__builtin_nontemporal_store((wu[0] + wu[8] + lu + ru) * 0.25 + 1.0, out_u + (size_t)r * nx + oc);
+				__builtin_nontemporal_store((wv[0] + wv[8] + lv + rv) * 0.25 + 1.0, out_v + (size_t)r * nx + oc);
+#else
 				out_u[(size_t)r * nx + oc] = (wu[0] + wu[8] + lu + ru) * 0.25 + 1.0;
 				out_v[(size_t)r * nx + oc] = (wv[0] + wv[8] + lv + rv) * 0.25 + 1.0;
+#endif
 			}
 		}
 	}
