@@ -538,30 +538,31 @@ const char *tuning_knob(const char *name) { return tuning_enabled() ? std::geten
 // fit into one with chunks of up to 96 rows gets those longer chunks -- no tail round on an almost idle chip.
 int device_cus()
 {
-	static int cus = 0;  // compute units of a device of this node (the GPUs of a node are alike)
-	if (cus == 0) {
+	// compute units of a device of this node (the GPUs of a node are alike); initialised once, also when several issuing threads of a
+	// LOCAL group arrive together
+	static const int cus = [] {
 		int dev = 0;
 		hipDeviceProp_t prop;
-		cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+		const int n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
 		(void)hipGetLastError();
-	}
+		return n;
+	}();
 	return cus;
 }
 
 template <typename Real, int MODEL, int COLS>
 int resident_wavefronts()
 {
-	static int slots = 0;  // resident wavefronts of this kernel on the current device
-	if (slots == 0) {
-		int dev = 0, cus = 256, blocks_per_cu = 4;
-		hipDeviceProp_t prop;
-		if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+	// resident wavefronts of this kernel on a device of this node (initialised once, thread-safely: the issuing threads of a LOCAL group
+	// may arrive together)
+	static const int slots = [] {
+		int blocks_per_cu = 4;
 		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0, COLS, false>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
 		    blocks_per_cu < 1)
 			blocks_per_cu = 4;
 		(void)hipGetLastError();
-		slots = cus * blocks_per_cu * kWavesPerBlock;
-	}
+		return device_cus() * blocks_per_cu * kWavesPerBlock;
+	}();
 	return slots;
 }
 
