@@ -11,7 +11,9 @@
  * known answers the reference's own code implies (steady states, index-space eigenfunctions), and
  * (iii) the shipped .ini parameter sets under data/, including the one result they state (the Goldbeter kinetics are
  * "oscillatory when 0.28895 < beta < 0.77427", data/GoldbeterModelArgs.ini:25 -- reproduced to the digits given, as is the
- * FHN Hopf point beta = 1 of util/FHNmodel/plot_FHNmodel_torus.py:90-92) -- not by outputs of the reference itself.
+ * FHN Hopf point beta = 1 of util/FHNmodel/plot_FHNmodel_torus.py:90-92; the torus's Gaussian curvature of
+ * util/PlotGaussianAndCoupling.py:11-12, which fixes the two theta-dependent coefficients of the diffusion operator) -- not by
+ * outputs of the reference itself.
  *
  * Every function cites the reference lines it follows (paths under /root/reference/).
  */

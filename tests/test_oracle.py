@@ -290,3 +290,82 @@ def test_arkode_restatement_behaves_like_the_documented_controller():
     tight = ark.ArkodeErk(p, 0.0, y0, rtol=1e-8, atol=1e-12)
     y3t, _ = tight.evolve(3.0)
     assert tight.nst > integ.nst and rel_err(y3t, fine) < 0.05 * rel_err(y3, fine) + 1e-9
+
+
+def curvature_reference_tables(theta, r, R, substeps=16):
+    """What the reference's utilities state about the torus, turned into the two theta-dependent coefficients of the diffusion
+    operator WITHOUT using the operator's own formulas.  util/PlotGaussianAndCoupling.py:11-12 (= util/GenCurvatureCoupling.py:87)
+    give the Gaussian curvature G(theta) = cos(theta) / (r (R + r cos(theta))).  On a surface of revolution with metric
+    ds^2 = r^2 dtheta^2 + rho(theta)^2 dphi^2 the Laplace-Beltrami operator is
+        (1/r^2) u_thth + b(theta) u_th + rho(theta)^-2 u_phph,     b = rho' / (rho r^2),     G = -rho'' / (rho r^2),
+    so G alone, with rho(0) = R + r (the outer equator: (surfaceLength + surfaceWidth) / 2 pi) and rho'(0) = 0 (symmetry), fixes
+    both: rho'' = -G rho r^2 is integrated here (classical RK4, `substeps` per grid interval) up to every theta_i.
+    Returns (b(theta_i), rho(theta_i)^-2)."""
+    def G(t):
+        return np.cos(t) / (r * (R + r * np.cos(t)))
+
+    def rhs(t, y):
+        return np.array([y[1], -G(t) * y[0] * r * r])
+
+    y, t = np.array([R + r, 0.0]), 0.0
+    b, inv_rho2 = np.empty_like(theta), np.empty_like(theta)
+    for i, ti in enumerate(theta):
+        if ti > t:
+            h = (ti - t) / substeps
+            for _ in range(substeps):
+                k1 = rhs(t, y)
+                k2 = rhs(t + h / 2, y + h / 2 * k1)
+                k3 = rhs(t + h / 2, y + h / 2 * k2)
+                k4 = rhs(t + h, y + h * k3)
+                y = y + h / 6 * (k1 + 2 * k2 + 2 * k3 + k4)
+                t += h
+        b[i] = y[1] / (y[0] * r * r)
+        inv_rho2[i] = 1.0 / (y[0] * y[0])
+    return b, inv_rho2
+
+
+def coefficients_implied_by_f(f, g, diffusion):
+    """The two theta-dependent coefficients as `f` applies them, recovered from two evaluations of the diffusion-only right-hand
+    side treated as a black box: on u = sin(theta_i) (no phi dependence) the phi term vanishes and
+        f_u / D = (1/r^2) (u_E - 2u + u_W)/dx^2 + b_i (u_E - u_W)/(2 dx)     =>  b_i;
+    on u = sin(phi_j) the theta terms vanish and f_u / D = c_i (u_N - 2u + u_S)/dy^2  =>  c_i.  The differences are formed from
+    the very field values handed to f, so nothing is lost to truncation; columns / rows next to the periodic seam are left out."""
+    nx, ny = int(g.nx), int(g.ny)
+    theta, phi = g.xmin + np.arange(nx) * g.dx, g.ymin + np.arange(ny) * g.dy
+    y = np.zeros((ny, nx, 2))
+    y[..., 0] = np.sin(theta)[None, :]
+    y[..., 1] = 0.7
+    fu = f(y)[ny // 2, :, 0] / diffusion
+    u = np.sin(theta)
+    i = np.arange(2, nx - 2)
+    i = i[np.abs(np.cos(theta[i])) > 0.2]
+    b = (fu[i] - (u[i + 1] - 2 * u[i] + u[i - 1]) / (g.dx * g.dx) / (g.r * g.r)) / ((u[i + 1] - u[i - 1]) / (2 * g.dx))
+    y[..., 0] = np.sin(phi)[:, None]
+    fphi = f(y)[:, :, 0] / diffusion
+    w = np.sin(phi)
+    j = np.arange(2, ny - 2)
+    j = j[np.abs(w[j]) > 0.3][0]
+    c = fphi[j, :] / ((w[j + 1] - 2 * w[j] + w[j - 1]) / (g.dy * g.dy))
+    return i, theta, b, c
+
+
+@pytest.mark.parametrize("L,W", [(80.0, 20.0), (40.0, 20.0)])
+def test_diffusion_operator_reproduces_the_gaussian_curvature_the_reference_states(L, W):
+    """A known answer for the DIFFUSION part of `f` from the reference tree itself: its plotting utilities state the torus's
+    Gaussian curvature, G = cos(theta) / (r (R + r cos(theta))) (util/PlotGaussianAndCoupling.py:11-12, util/GenCurvatureCoupling.py:87,
+    for the two tori it uses: surfaceLength 80 and 40, surfaceWidth 20).  G fixes the theta-advection coefficient and the phi-phi
+    coefficient of the Laplace-Beltrami operator (curvature_reference_tables); the coefficients the restated `f` applies
+    (src/FHNmodel_torus.cpp:527-615 = src/GoldbeterModel_torus.cpp:571-659) must be those -- in the C restatement and in the numpy one."""
+    nx, ny, D = 400, 24, 0.12
+    op = co.make_problem(co.GOLDBETER, co.TORUS, nx, L, W, D, 0.4, ny=ny, just_diffusion=1)
+    gn = cn.geometry("torus", L, W, nx, ny)
+
+    def f_numpy(y):
+        du, dv = cn.rhs("goldbeter", "torus", gn, D, 0.0, y[..., 0], y[..., 1], beta=0.4, just_diffusion=1)
+        return np.stack([du, dv], axis=-1)
+
+    for f in (lambda y: co.rhs(op, 0.0, y), f_numpy):
+        i, theta, b, c = coefficients_implied_by_f(f, op, D)
+        b_ref, c_ref = curvature_reference_tables(theta, op.r, op.R)
+        assert np.max(np.abs(b - b_ref[i])) <= 1e-9 * np.max(np.abs(b_ref)), float(np.max(np.abs(b - b_ref[i])))
+        assert np.max(np.abs(c[2:-2] / c_ref[2:-2] - 1.0)) <= 1e-9
