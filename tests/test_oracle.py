@@ -324,6 +324,17 @@ def curvature_reference_tables(theta, r, R, substeps=16):
     return b, inv_rho2
 
 
+def coupling_strength_as_the_reference_plots_it(theta, r, R):
+    """util/PlotGaussianAndCoupling.py:15-19 (= util/GenCurvatureCoupling.py:30-40,90): the "coupling strength" of Kneer et al. in
+    the torus's isothermal coordinates, C = 10 (cosh(eta) - cos(theta_i))^2 / a^2 with a = sqrt(R^2 - r^2), eta = atanh(a / R),
+    theta_i = arccos(R/r - a^2 / (r (R + r cos(theta)))).  It is the inverse of the conformal factor, hence proportional to the
+    phi-phi coefficient of the Laplace-Beltrami operator, (R + r cos(theta))^-2 (the factor is 10 a^2 / r^2)."""
+    a = np.sqrt(R * R - r * r)
+    eta = np.arctanh(a / R)
+    theta_i = np.arccos(np.clip(R / r - a * a / (r * (R + r * np.cos(theta))), -1.0, 1.0))
+    return 10.0 * (np.cosh(eta) - np.cos(theta_i)) ** 2 / (a * a)
+
+
 def coefficients_implied_by_f(f, g, diffusion):
     """The two theta-dependent coefficients as `f` applies them, recovered from two evaluations of the diffusion-only right-hand
     side treated as a black box: on u = sin(theta_i) (no phi dependence) the phi term vanishes and
@@ -369,3 +380,7 @@ def test_diffusion_operator_reproduces_the_gaussian_curvature_the_reference_stat
         b_ref, c_ref = curvature_reference_tables(theta, op.r, op.R)
         assert np.max(np.abs(b - b_ref[i])) <= 1e-9 * np.max(np.abs(b_ref)), float(np.max(np.abs(b - b_ref[i])))
         assert np.max(np.abs(c[2:-2] / c_ref[2:-2] - 1.0)) <= 1e-9
+        # ... and the phi-phi coefficient has the shape of the "coupling strength" the same utilities plot
+        cs = coupling_strength_as_the_reference_plots_it(theta, op.r, op.R)
+        mid = len(theta) // 3
+        assert np.max(np.abs((c[2:-2] / c[mid]) / (cs[2:-2] / cs[mid]) - 1.0)) <= 1e-11
