@@ -427,3 +427,34 @@ def test_seeded_sweep_of_host_side_rules_against_the_oracle():
                 assert np.array_equal(got, want[: j1 + 1]), case
         else:
             assert np.array_equal(got, want[j0:j1 + 1]), (case, model, surface, vary, ic_type)
+
+
+def test_initial_wave_and_beta_ramp_are_what_the_parameter_files_document():
+    """The shipped parameter files describe their keys in comments (data/FHNmodelArgs.ini:24-41, data/GoldbeterModelArgs.ini:23-41),
+    independently of the C++ source: waveLength / waveWidth are the initial wave segment's length / width "as a percentage of total
+    length of torus (phi)" / "of total width of torus (theta)", waveInside centres it on the inside (theta = pi) or the outside
+    (theta = 0) of the torus, and varyBeta varies beta "linearly over the surface" between betaMin and betaMax.  The host-side
+    initial-condition rule and the row parameter the right-hand side applies are exactly that."""
+    nx, ny = 400, 1600
+    for inside in (0, 1):
+        for wl, ww in ((0.1, 0.5), (0.25, 0.2)):
+            p = crd.make_params("fhn", "torus", nx, 80.0, 20.0, 0.12, 1.25, ny=ny)
+            y = crd.initial_conditions(crd.run_config(p, wave_length=wl, wave_width=ww, wave_inside=inside))
+            us, vs = crd.steady_state("fhn", 1.25)
+            wave = (y[..., 0] != us) | (y[..., 1] != vs)
+            cols, rows = np.flatnonzero(wave.any(axis=0)), np.flatnonzero(wave.any(axis=1))
+            assert wave.sum() == len(cols) * len(rows)  # a rectangle in (theta, phi)
+            assert abs(len(rows) / ny - wl) <= 2.0 / ny and abs(len(cols) / nx - ww) <= 2.0 / nx  # the documented fractions of the surface
+            theta = np.arange(nx) * 2 * np.pi / (nx - 1)
+            if inside:  # centred on theta = pi
+                assert abs(theta[cols].mean() - np.pi) <= 2 * np.pi / nx and np.all(np.diff(cols) == 1)
+            else:  # centred on theta = 0 = 2 pi: the segment wraps around the seam
+                assert cols[0] == 0 and cols[-1] == nx - 1 and abs(np.cos(theta[cols]).mean() - np.sinc(ww)) <= 0.02
+    # beta varied linearly over phi between betaMin and betaMax: read off the FHN inhibitor equation, v' = 0.36 (u + b(phi))
+    from oracle import crd_oracle as co
+
+    op = co.make_problem(co.FHN, co.TORUS, 40, 80.0, 20.0, 0.12, 1.25, ny=160, vary_beta=1, beta_min=0.7, beta_max=1.7)
+    yy = np.zeros((160, 40, 2))
+    yy[..., 0], yy[..., 1] = 0.3, -0.2
+    b = co.rhs(op, 1e9, yy)[:, 5, 1] / 0.36 - 0.3
+    assert abs(b[0] - 0.7) <= 1e-12 and abs(b[-1] - 1.7) <= 1e-12 and np.max(np.abs(np.diff(b, 2))) <= 1e-12  # end points and linearity
