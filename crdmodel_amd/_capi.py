@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # CRD_LIBRARY points the binding at another build of the same ABI (tuning builds under tools/); default is the in-tree library.
 LIB_PATH = os.environ.get("CRD_LIBRARY") or os.path.join(_PKG, "libcrd.so")
 
-ABI_VERSION = 3  # CRD_ABI_VERSION of include/crd.h (tests/test_host_abi.py keeps the two in step)
+ABI_VERSION = 4  # CRD_ABI_VERSION of include/crd.h (tests/test_host_abi.py keeps the two in step)
 OK, EINVAL, ENOMEM, EHIP, ERCCL, EIO, EPARSE, ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
 MODEL_FHN, MODEL_GOLDBETER = 0, 1
 SURFACE_TORUS, SURFACE_FLAT = 0, 1
@@ -170,6 +170,10 @@ _SIGNATURES = {
     "crd_plan_launches": (C.c_int, [_vp]),
     "crd_set_diagnostics": (C.c_int, [_vp, C.c_int]),
     "crd_set_halo_slack": (C.c_int, [_vp, C.c_int]),
+    "crd_set_exchange_period": (C.c_int, [_vp, C.c_int]),
+    "crd_get_exchange_period": (C.c_int, [_vp]),
+    "crd_group_set_threads": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_int]),
+    "crd_launch_plan_candidate": (C.c_int, [C.c_int, C.POINTER(LaunchPlan)]),
     "crd_get_step_timing": (C.c_int, [_vp, C.POINTER(StepTiming)]),
 }
 

@@ -9,6 +9,7 @@
 #include <new>
 
 #include "crd_ctx.h"
+#include "crd_tuning.h"
 
 namespace crd {
 
@@ -84,7 +85,7 @@ int resolve_stepper(const crd_ctx *c)
 		int64_t js, je;
 		if (crd_slab_extents(c->g.ny, k, c->d1, &js, &je) == CRD_OK) shortest = std::min<int64_t>(shortest, je - js + 1);
 	}
-	const bool can_fuse = fused_step_supported(c->p.precision, c->desc) && (c->halo == CRD_HALO_SELF || shortest >= kGhost);
+	const bool can_fuse = fused_step_supported(c->p.precision, c->desc) && (c->halo == CRD_HALO_SELF || shortest >= kStepHalo * c->exchange_every);
 	if (c->stepper == CRD_STEPPER_FUSED) return can_fuse ? CRD_STEPPER_FUSED : -1;
 	return can_fuse ? CRD_STEPPER_FUSED : CRD_STEPPER_STAGED;
 }
@@ -166,14 +167,13 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	c->real_size = p->precision == CRD_PRECISION_F64 ? 8 : 4;
 	c->plane_bytes = (size_t)(c->nyl + 2 * kGhost) * (size_t)c->nx * c->real_size;
 	c->halo = n_slabs == 1 ? CRD_HALO_SELF : -1;  // multi-slab contexts must be wired before use
-	if (const char *e = std::getenv("CRD_BAND_STREAM")) c->bands_on_own_stream = std::atoi(e) != 0;
-	if (const char *e = std::getenv("CRD_HALO_SLACK")) c->halo_slack = std::atoi(e) == 2 ? 2 : 1;
-	if (const char *e = std::getenv("CRD_AUTOTUNE")) c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = std::atoi(e) != 0;
+	if (const char *e = std::getenv("CRD_AUTOTUNE"))  // 0 / 1 / 2, as crd_set_autotune
+		c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = std::atoi(e) <= 0 ? 0 : (std::atoi(e) >= 2 ? 2 : 1);
 	// CRD_LAUNCH_PLAN=mode,mapping,columns,nt: what crd_set_launch_plan does, for a program one cannot change (crd_run under a profiler)
 	if (const char *e = std::getenv("CRD_LAUNCH_PLAN")) {
 		int m = -1, k = -1, cols = -1, nt = 0;
 		if (std::sscanf(e, "%d,%d,%d,%d", &m, &k, &cols, &nt) >= 3 && m >= 0 && m <= 2 && k >= 0 && k <= 2 && cols >= 1 && cols <= 2 && nt >= 0 && nt <= 1) {
-			c->plan.tuned = 1;
+			c->plan.tuned = c->plan.pinned = 1;
 			c->plan.one_round = m;
 			c->plan.remap = k;
 			c->plan.cols = cols;
@@ -205,11 +205,11 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	c->comm = c->streams->comm;
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_edges, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreateWithFlags(&c->ev_halo, hipEventDisableTiming));
-	CREATE_TRY(hipEventCreateWithFlags(&c->ev_interior, hipEventDisableTiming));
 	CREATE_TRY(hipEventCreate(&c->ev_t0));
 	CREATE_TRY(hipEventCreate(&c->ev_t1));
-	c->plane_skew = 16640;  // 16 KiB + 256 B (profiles/r03/plane_skew.txt: -3 % at 8192^2 fp64 on one box, -5 % Goldbeter 4096^2 on another, nowhere a loss beyond run-to-run noise)
-	if (const char *e = std::getenv("CRD_PLANE_SKEW")) c->plane_skew = (size_t)std::max(0L, std::atol(e)) & ~(size_t)255;  // (rows stay 256-byte aligned)
+	// 16 KiB + 256 B (profiles/r03/plane_skew.txt: -3 % at 8192^2 fp64 on one box, -5 % Goldbeter 4096^2 on another, nowhere a loss beyond
+	// run-to-run noise); rows stay 256-byte aligned
+	c->plane_skew = (size_t)tuning::plane_skew(16640) & ~(size_t)255;
 	for (int k = 0; k < crd_ctx::OUT; k++)  // (the OUT plane is allocated by the first dense-output call)
 		for (int f = 0; f < 2; f++)
 			if ((rc = alloc_plane(c, k, f))) return bail(rc);
@@ -273,7 +273,6 @@ void crd_destroy(crd_ctx *c)
 	(void)hipGetLastError();
 	if (c->compute) (void)hipStreamSynchronize(c->compute);
 	if (c->comm) (void)hipStreamSynchronize(c->comm);
-	if (c->band) (void)hipStreamSynchronize(c->band);
 	if (c->nccl && g_rccl.handle) (void)g_rccl.CommDestroy(c->nccl);
 	for (void *q : c->plane_allocs) (void)hipFree(q);
 	if (c->scalar_host) (void)hipHostFree(c->scalar_host);
@@ -288,9 +287,6 @@ void crd_destroy(crd_ctx *c)
 			if (q) (void)hipFree(q);
 	for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->ev_diag) (void)hipEventDestroy(e);
-	if (c->flag_dev) (void)hipFree(c->flag_dev);
-	if (c->halo_flag_dev) (void)hipFree(c->halo_flag_dev);
-	if (c->flag_counter) (void)hipFree(c->flag_counter);
 	if (c->ev_agree) (void)hipEventDestroy(c->ev_agree);
 	if (c->agree_dev) (void)hipFree(c->agree_dev);
 	if (c->agree_host) (void)hipHostFree(c->agree_host);
@@ -299,7 +295,7 @@ void crd_destroy(crd_ctx *c)
 		(void)hipStreamSynchronize(c->down);
 		(void)hipStreamDestroy(c->down);
 	}
-	for (hipEvent_t e : {c->ev_edges, c->ev_halo, c->ev_interior, c->ev_t0, c->ev_t1})
+	for (hipEvent_t e : {c->ev_edges, c->ev_halo, c->ev_t0, c->ev_t1})
 		if (e) (void)hipEventDestroy(e);
 	c->streams.reset();  // destroys the streams unless another context of a LOCAL group on this device still uses them
 	// detach from a LOCAL group so the survivors do not dereference this context
@@ -336,18 +332,14 @@ int crd_comm_attach_local(crd_ctx *const *ctxs, int n)
 			return fail(ctxs[0], CRD_EINVAL, "contexts of one run must share the grid, the decomposition and the precision");
 		c->group.assign(ctxs, ctxs + n);
 		c->halo = CRD_HALO_LOCAL;
-		// (experiment knob CRD_GROUP_OWN_STREAMS=1: every slab keeps its own streams also on a shared device, so that one slab's
-		// launch can fill the chip while another's drains)
-		static const bool own_streams = std::getenv("CRD_GROUP_OWN_STREAMS") && std::atoi(std::getenv("CRD_GROUP_OWN_STREAMS")) != 0;
-		for (int j = 0; j < k && !own_streams; j++)
+		for (int j = 0; j < k; j++)
 			if (ctxs[j]->device == c->device) {  // slabs on one device run on one set of streams
 				if (hipSetDevice(c->device) != hipSuccess) return fail(ctxs[0], CRD_EHIP, "hipSetDevice failed");
-				for (hipStream_t s : {c->compute, c->comm, c->band})
+				for (hipStream_t s : {c->compute, c->comm})
 					if (s) (void)hipStreamSynchronize(s);
 				c->streams = ctxs[j]->streams;
 				c->compute = c->streams->compute;
 				c->comm = c->streams->comm;
-				c->band = nullptr;  // picked up from the shared set on first use
 				break;
 			}
 	}
@@ -409,7 +401,7 @@ int crd_comm_info(const crd_ctx *c, int *halo, int *ranks, int *rank)
 int crd_halo_exchange(crd_ctx *c, int depth)
 {
 	if (!c) return CRD_EINVAL;
-	if (depth < 1 || depth > kGhost || depth > c->nyl) return fail(c, CRD_EINVAL, "halo depth out of range (1 .. 32, at most the slab's rows)");
+	if (depth < 1 || depth > kGhost || depth > c->nyl) return fail(c, CRD_EINVAL, "halo depth out of range (1 .. 64, at most the slab's rows)");
 	if (c->halo < 0) return fail(c, CRD_ESTATE, "multi-slab context is not wired (crd_comm_attach_local / crd_comm_init_rccl)");
 	if (c->halo == CRD_HALO_LOCAL) return fail(c, CRD_ESTATE, "LOCAL groups exchange inside crd_group_step_rk4");
 	if (int rc = set_device(c)) return rc;
@@ -430,7 +422,7 @@ int crd_halo_exchange(crd_ctx *c, int depth)
 	HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
 	HIP_TRY(c, hipStreamSynchronize(c->comm));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));
-	if (depth == kGhost) c->cycle_pos = 0;  // a full deep-halo exchange: the fused stepper may start its cycle from here
+	if (depth == kStepHalo * c->exchange_every) c->cycle_pos = 0;  // a full deep-halo exchange: the fused stepper may start its cycle from here
 	return CRD_OK;
 }
 
@@ -673,7 +665,6 @@ int crd_synchronize(crd_ctx *c)
 	if (!c) return CRD_EINVAL;
 	if (int rc = set_device(c)) return rc;
 	HIP_TRY(c, hipStreamSynchronize(c->comm));
-	if (c->band) HIP_TRY(c, hipStreamSynchronize(c->band));
 	HIP_TRY(c, hipStreamSynchronize(c->compute));
 	return CRD_OK;
 }
@@ -681,8 +672,8 @@ int crd_synchronize(crd_ctx *c)
 int crd_set_autotune(crd_ctx *c, int on)
 {
 	if (!c) return CRD_EINVAL;
-	c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = on != 0;
-	if (!on) c->plan.tuned = c->plan_embed.tuned = c->plan_arkode.tuned = 0;  // back to the plain plan
+	c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = on <= 0 ? 0 : (on >= 2 ? 2 : 1);  // 2: print the timings to stderr
+	if (on <= 0) c->plan.tuned = c->plan_embed.tuned = c->plan_arkode.tuned = c->plan.pinned = 0;  // back to the plain plan
 	return CRD_OK;
 }
 
@@ -692,13 +683,16 @@ int crd_set_launch_plan(crd_ctx *c, int chunk_mode, int xcd_mapping, int columns
 	if (chunk_mode < 0 || chunk_mode > 2 || xcd_mapping < 0 || xcd_mapping > 2 || columns_per_lane < 1 || columns_per_lane > 2 || nontemporal_stores < 0 ||
 	    nontemporal_stores > 1)
 		return fail(c, CRD_EINVAL, "crd_set_launch_plan: chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1");
-	c->plan.tuned = 1;
-	c->plan.one_round = chunk_mode;
-	c->plan.remap = xcd_mapping;
-	c->plan.cols = columns_per_lane;
-	c->plan.nt = nontemporal_stores;
-	c->plan.rows = c->nyl;  // (launches within a tenth of this height take the plan: the sweeps of a deep-halo cycle do)
-	c->plan.ms_default = c->plan.ms_best = 0.f;
+	// (the error-controlled integrators' instantiations take the plan too; they step one column per lane whatever it says)
+	for (FusedPlan *pl : {&c->plan, &c->plan_embed, &c->plan_arkode}) {
+		pl->tuned = pl->pinned = 1;
+		pl->one_round = chunk_mode;
+		pl->remap = xcd_mapping;
+		pl->cols = columns_per_lane;
+		pl->nt = nontemporal_stores;
+		pl->rows = c->nyl;  // (a pinned plan applies to launches of every height)
+		pl->ms_default = pl->ms_best = 0.f;
+	}
 	return CRD_OK;
 }
 
@@ -710,11 +704,20 @@ int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
 	out->one_round = c->plan.one_round;
 	out->xcd_mapping = c->plan.remap;
 	out->rows = c->plan.rows;
-	out->columns_per_lane = c->plan.cols;
+	// (without a plan the launches take the default of their precision: two columns per lane in fp32 on an even nx)
+	out->columns_per_lane = c->plan.tuned ? c->plan.cols : fused_default_columns(c->p.precision, c->nx);
 	out->nontemporal_stores = c->plan.nt;
 	out->reserved = 0;
 	out->ms_default = c->plan.ms_default;
 	out->ms_chosen = c->plan.ms_best;
+	return CRD_OK;
+}
+
+int crd_launch_plan_candidate(int index, crd_launch_plan *out)
+{
+	if (!out) return CRD_EINVAL;
+	*out = crd_launch_plan{};
+	if (!fused_plan_candidate(index, &out->one_round, &out->xcd_mapping, &out->columns_per_lane, &out->nontemporal_stores)) return CRD_EINVAL;
 	return CRD_OK;
 }
 

@@ -79,16 +79,15 @@ struct GroupBarrier {
 	}
 };
 
-// The three streams of a context: interior sweeps, edge bands (high priority), halo exchange.  Contexts of a LOCAL group
-// that share a device share one set (crd_comm_attach_local), so a device never carries more than three of this library's
-// streams however many slabs it hosts.
+// The two streams of a context: sweeps, halo exchange.  Contexts of a LOCAL group that share a device share one set
+// (crd_comm_attach_local), so a device never carries more than two of this library's streams however many slabs it hosts.
 struct StreamSet {
 	int device = 0;
-	hipStream_t compute = nullptr, comm = nullptr, band = nullptr;
+	hipStream_t compute = nullptr, comm = nullptr;
 	~StreamSet()
 	{
 		(void)hipSetDevice(device);
-		for (hipStream_t s : {compute, comm, band})
+		for (hipStream_t s : {compute, comm})
 			if (s) {
 				(void)hipStreamSynchronize(s);
 				(void)hipStreamDestroy(s);
@@ -134,12 +133,8 @@ struct crd_ctx {
 	int err_capacity = 0;
 
 	std::shared_ptr<StreamSet> streams;                               // owner of the handles below
-	hipStream_t compute = nullptr, comm = nullptr, band = nullptr;
-	// Edge bands are launched on the compute stream ahead of the interior sweep.  CRD_BAND_STREAM=1 moves them to a third,
-	// high-priority stream (measured on one GPU with an RCCL self-ring: no gain at 8192 x 1024..4096 slabs, and the time then
-	// depends on when the runtime maps that stream to a hardware queue), kept as a knob for multi-GPU experiments.
-	bool bands_on_own_stream = false;
-	hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_interior = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
+	hipStream_t compute = nullptr, comm = nullptr;
+	hipEvent_t ev_edges = nullptr, ev_halo = nullptr, ev_t0 = nullptr, ev_t1 = nullptr;
 	std::vector<hipEvent_t> ev_k;  // per-launch timing events
 	hipStream_t down = nullptr;    // device-to-host stream of the pipelined crd_rhs_host (lazy)
 	std::vector<hipEvent_t> ev_band;  // its per-band events (lazy)
@@ -167,26 +162,13 @@ struct crd_ctx {
 	// Halo slack: sweeps of owned-only rows the compute stream launches after an exchange before it waits for the halo -- 1: the
 	// cycle's first step is split (rounds 1-2); 2: the first two are, for a third sweep of cover (crd_set_halo_slack, CRD_HALO_SLACK).
 	int halo_slack = 1;
+	int exchange_every = crd::kDefaultExchangeEvery;  // E: fused steps per deep-halo exchange (crd_set_exchange_period), the same on every slab of a run
+	int group_threads = 0;  // lead context of a LOCAL group: issuing threads of crd_group_step_rk4 (0 = one per device)
 	bool ghost_deferred = false;  // step 0 of the cycle has launched its owned-only rows; its ghost readers wait for step 1
 	double deferred_t = 0.0;      // that step's time
 	int cycle_pos = -1;
 	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
 	int cycle_start = -1;  // the decision for the call in progress, taken for ALL slabs of the run before any thread issues (run_steps)
-	// Flag-triggered exchange (RCCL runs, one-launch stepper): the last step of an exchange cycle is ONE launch whose first blocks
-	// are the edge bands; when those are in memory the kernel writes flag_epoch to *flag_dev (signal memory) and the halo
-	// exchange, parked on the comm stream with hipStreamWaitValue64, goes ahead under the rest of the launch.  flag_mode: -1 not
-	// tried yet, 0 unavailable / switched off (CRD_FLAG_EXCHANGE=0): separate band launch + event, as in rounds 1-2; bit 0: this.
-	// Bit 1 of flag_mode: the same primitive the other way round -- the comm stream writes halo_epoch to *halo_flag_dev behind
-	// the exchange (hipStreamWriteValue64) and the compute stream waits for that value instead of for an event.
-	int flag_mode = -1;
-	unsigned long long *halo_flag_dev = nullptr;
-	unsigned long long halo_epoch = 0;
-	unsigned long long *flag_dev = nullptr;
-	unsigned *flag_counter = nullptr;
-	unsigned long long flag_epoch = 0;
-	bool flag_pending = false;  // the exchange about to be issued waits for the flag, not for ev_edges
-	bool merged_step = false;   // ... and the step it belongs to went out as one launch (no separate interior launch to follow)
-
 	// RCCL runs: the ranks AGREE on the cycle position at the start of every stepping call (one 2-value ncclAllReduce(min) of
 	// (pos, -pos) on the comm stream, overlapped with the call's first step where that step involves no exchange): a rank whose
 	// state is new -- an upload on that rank only, a failed call -- makes every rank start afresh with an exchange instead of

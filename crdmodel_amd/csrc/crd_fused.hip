@@ -23,6 +23,7 @@
 #include <utility>
 
 #include "crd_device.h"
+#include "crd_tuning.h"
 
 namespace crd {
 
@@ -160,27 +161,18 @@ struct FusedArgs {
 	Real h2, h3, h6, h1;      // dt/2, dt/3, dt/6, dt
 	int absorb[5];            // t_stage < tBoundary for the four stages (+ the embedded pair's fifth)
 	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
-	// Rows this launch produces: up to three ranges, each cut into work items ("chunks") of its own length; chunk ids run through
-	// the ranges in order (range k holds ids [first[k], first[k+1])).  One range: an ordinary sweep.  Two: the rows of a step that
-	// read ghost rows, below and above the slab.  Three: the last step of an exchange cycle as ONE launch -- the two edge bands
-	// first (short chunks, lowest block ids: dispatched first) and the interior behind them.
-	int r_begin[3], r_end[3], r_chunk[3], r_first[3];
+	// Rows this launch produces: one or two ranges, cut into work items ("chunks") of `chunk` rows; chunk ids run through the
+	// ranges in order (range 1 starts at id `first2`).  One range: an ordinary sweep.  Two: the rows of a step that read ghost
+	// rows, below and above the slab, or the two edge bands of a cycle's last step.
+	int r_begin[2], r_end[2], chunk, first2;
 	int nstrips, nitems, nblocks, remap;
 	int xs_lanes;             // remap 2: phi-lanes of chunk sequences per strip block and XCD
-	int nchunks;              // chunks of all ranges
+	int nchunks;              // chunks of both ranges
 	int sw;                   // wavefronts per block = adjacent strips a block covers
-	// Flag-triggered exchange: blocks of the chunks [0, flag_chunks) -- the edge bands -- count themselves in when their rows are
-	// in memory; the last one writes flag_value to `flag` (signal memory), which releases the halo exchange waiting on the
-	// second stream (hipStreamWaitValue64) while the interior blocks of this same launch are still running.
-	int flag_chunks, flag_blocks;
-	unsigned *flag_counter;
-	unsigned long long *flag, flag_value;
 	double *err_partials;     // EMBED: one weighted square sum per work item
 	Real rtol, atol;          // EMBED: error weights 1 / (rtol |y_n| + atol)
 };
 
-// ABSORB = false compiles the absorbing-row selects out (no stage of the step has t < tBoundary: every launch after the
-// switch-off time, and every launch of a run with tBoundary = 0).
 // EMBED adds a fifth pipeline stage and with it a local error estimate whose weighted square sum
 //   sum_i (err_i / (rtol |y_n,i| + atol))^2
 // over this work item's outputs is written to err_partials[item] (ARKode's WRMS norm, src/FHNmodel_torus.cpp:365, is
@@ -203,8 +195,12 @@ struct FusedArgs {
 // direction for two columns, and the fp32 arithmetic is the packed instructions (v_pk_fma_f32 ...).  Needs an even nx (the
 // pair must not straddle the periodic seam); results are the one-column kernel's bit for bit.
 // NT = true: the new state is stored with the non-temporal hint (row_store above).
-template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false>
-__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
+// One work item: strip `strip` (a wavefront's columns) of chunk `chunk` (its rows).  ABSORB as a template argument of the ITEM: a
+// launch some stage of which has t < tBoundary runs the selects only in the items whose rows (aprons included) contain a global
+// phi boundary row -- two chunks per boundary of a launch; every other item runs the body without them (the kernel below decides
+// per chunk, uniformly for the block).  With the selects in every item the absorbing-rows run cost 5.4 % at 8192^2 (round 3).
+template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT>
+__device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk)
 {
 	static_assert(COLS == 1 || (COLS == 2 && EMBED == 0), "the embedded pairs run one column per lane");
 	using V = typename LaneValue<Real, COLS>::type;
@@ -219,40 +215,6 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	constexpr int kPrefetch = EMBED != 0 ? ((MODEL == CRD_MODEL_GOLDBETER && sizeof(Real) == 8) ? 2 : CRD_PREFETCH_EMBED) : (MODEL == CRD_MODEL_GOLDBETER) ? CRD_PREFETCH_GB : CRD_PREFETCH_FHN;
 	static_assert(M % kPrefetch == 0, "prefetch slots are addressed with the unrolled iteration index");
 	const int lane = threadIdx.x & (kLanes - 1);
-	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
-	// per-row table reads, the boundary-row tests) in scalar registers.
-	// Optional remap: blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of items.
-	// A block's wavefronts take adjacent strips of ONE chunk, blocks walk theta first.  The wavefronts of a block therefore
-	// run the same trip counts, and in lockstep (one barrier per pipeline iteration) their row reads reach the memory system
-	// together as one contiguous, overlapping run of a.sw x 448 B per row instead of drifting apart.
-	const int nsb = (a.nstrips + a.sw - 1) / a.sw;
-	// (the edge-band blocks of a merged launch keep their dispatch order; the mapping applies to the blocks behind them)
-	const int band_blocks = a.flag_blocks, mapped_blocks = a.nblocks - band_blocks, mapped_chunks = a.nchunks - a.flag_chunks;
-	int sblk, cblk;
-	if ((int)blockIdx.x < band_blocks) {
-		sblk = (int)blockIdx.x % nsb;
-		cblk = (int)blockIdx.x / nsb;
-	} else {
-		const int b0 = (int)blockIdx.x - band_blocks;
-		const int blk = a.remap == 1 ? xcd_remap(b0, mapped_blocks) : b0;
-		sblk = blk % nsb;
-		cblk = blk / nsb;
-		if (a.remap == 2) {
-			// Succession in phi: XCD x owns a contiguous run of chunks; its resident workgroups form `xs_lanes` lanes per strip
-			// block, and the workgroup that takes a finished one's place (ids are dispatched in order, 8 apart on one XCD) continues
-			// that lane with the NEXT chunk in phi -- whose first rows are the rows its predecessor has just read into this L2.
-			const int x = blk % kNumXcd, p = blk / kNumXcd, width = nsb * a.xs_lanes;
-			const int d = p / width, sl = p - d * width;
-			const int c0 = (int)((long)mapped_chunks * x / kNumXcd), c1 = (int)((long)mapped_chunks * (x + 1) / kNumXcd);
-			const int depth = (c1 - c0 + a.xs_lanes - 1) / a.xs_lanes, lane_id = sl / nsb;
-			sblk = sl - lane_id * nsb;
-			cblk = (d < depth && c0 + lane_id * depth + d < c1) ? c0 + lane_id * depth + d : mapped_chunks;  // mapped_chunks: nothing to do
-		}
-		cblk += a.flag_chunks;
-	}
-	const int strip = __builtin_amdgcn_readfirstlane(sblk * a.sw + (int)(threadIdx.x >> 6));
-	const int chunk = __builtin_amdgcn_readfirstlane(cblk);
-	if (strip >= a.nstrips || chunk >= a.nchunks) return;  // (a barrier waits for the surviving wavefronts of the workgroup only)
 	const int item = chunk * a.nstrips + strip;
 	const int nx = s.nx;
 
@@ -265,10 +227,10 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	const int out_col = strip * VALID + (COLS * lane - APRON);
 	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;  // (two columns: nx is even, so is out_col)
 
-	const int range = (chunk >= a.r_first[2]) ? 2 : (chunk >= a.r_first[1]) ? 1 : 0;  // (unused ranges start at nchunks)
-	const int range_end = a.r_end[range], range_chunk = a.r_chunk[range];
-	const int j0 = a.r_begin[range] + (chunk - a.r_first[range]) * range_chunk;
-	const int j1 = (j0 + range_chunk < range_end) ? j0 + range_chunk : range_end;
+	const int range = chunk >= a.first2 ? 1 : 0;  // (an unused second range starts at nchunks)
+	const int range_end = a.r_end[range];
+	const int j0 = a.r_begin[range] + (chunk - (range ? a.first2 : 0)) * a.chunk;
+	const int j1 = (j0 + a.chunk < range_end) ? j0 + a.chunk : range_end;
 	const int jbase = j0 - APRON;
 	const int niter = (j1 - j0) + 2 * APRON;
 	const int jlast = j1 + APRON - 1;  // last row the pipeline consumes
@@ -478,27 +440,63 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::false_type{});
 	    },
 	    std::make_integer_sequence<int, M - 1>{});
-	if (EMBED == 0 && chunk < a.flag_chunks) {
-		// An edge-band block of a merged launch (uniform over the block: its wavefronts share the chunk).  Every wavefront's stores
-		// have reached L2; then ONE wavefront writes this XCD's L2 back -- the bands must be in memory before the exchange kernel,
-		// which may run on any XCD or read them over the fabric, is let go -- and counts the block in.
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-		__builtin_amdgcn_s_barrier();
-		if (threadIdx.x == 0) {  // (the block's first wavefront always survives the strip test above: it has the lowest strip)
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-			const unsigned arrived = __hip_atomic_fetch_add(a.flag_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-			if (arrived == (unsigned)a.flag_blocks) {
-				__hip_atomic_store(a.flag_counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next cycle's launch
-				__hip_atomic_store(a.flag, a.flag_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-			}
-		}
-	}
 	if constexpr (EMBED != 0) {
 		// wavefront sum in a fixed order (butterfly over lane distances 32 .. 1), one partial per work item: the host-side
 		// reduction adds them in item order, so the norm is reproducible run to run
 		double sum = lane_total(err2);
 		for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
 		if (lane == 0) a.err_partials[item] = sum;
+	}
+}
+
+// ABSORB = false: no stage of the step has t < tBoundary (every launch after the switch-off time, every launch of a run with
+// tBoundary = 0) -- the absorbing-row selects are compiled out.  ABSORB = true: the items that can meet a global phi boundary row
+// (src/FHNmodel_torus.cpp:643-653) run the body with the selects, all others the body without (see fused_item).
+// EMBED, COLS, NT: see FusedArgs / fused_item above.
+template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false>
+__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
+{
+	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
+	// per-row table reads, the boundary-row tests) in scalar registers.
+	// Optional remap: blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of items.
+	// A block's wavefronts take adjacent strips of ONE chunk, blocks walk theta first.  The wavefronts of a block therefore
+	// run the same trip counts, and in lockstep (one barrier per pipeline iteration) their row reads reach the memory system
+	// together as one contiguous, overlapping run of a.sw x 448 B per row instead of drifting apart.
+	const int nsb = (a.nstrips + a.sw - 1) / a.sw;
+	int sblk, cblk;
+	{
+		const int b0 = (int)blockIdx.x;
+		const int blk = a.remap == 1 ? xcd_remap(b0, a.nblocks) : b0;
+		sblk = blk % nsb;
+		cblk = blk / nsb;
+		if (a.remap == 2) {
+			// Succession in phi: XCD x owns a contiguous run of chunks; its resident workgroups form `xs_lanes` lanes per strip
+			// block, and the workgroup that takes a finished one's place (ids are dispatched in order, 8 apart on one XCD) continues
+			// that lane with the NEXT chunk in phi -- whose first rows are the rows its predecessor has just read into this L2.
+			const int x = blk % kNumXcd, p = blk / kNumXcd, width = nsb * a.xs_lanes;
+			const int d = p / width, sl = p - d * width;
+			const int c0 = (int)((long)a.nchunks * x / kNumXcd), c1 = (int)((long)a.nchunks * (x + 1) / kNumXcd);
+			const int depth = (c1 - c0 + a.xs_lanes - 1) / a.xs_lanes, lane_id = sl / nsb;
+			sblk = sl - lane_id * nsb;
+			cblk = (d < depth && c0 + lane_id * depth + d < c1) ? c0 + lane_id * depth + d : a.nchunks;  // nchunks: nothing to do
+		}
+	}
+	const int strip = __builtin_amdgcn_readfirstlane(sblk * a.sw + (int)(threadIdx.x >> 6));
+	const int chunk = __builtin_amdgcn_readfirstlane(cblk);
+	if (strip >= a.nstrips || chunk >= a.nchunks) return;  // (a barrier waits for the surviving wavefronts of the workgroup only)
+	if constexpr (ABSORB) {
+		// Does any row this chunk's pipeline touches -- [j0 - APRON, j1 + APRON) -- map to global row 0 or ny - 1?  The two are
+		// neighbours on the periodic grid: the rows contain one of them exactly when [lo, hi + 1] contains a multiple of ny.
+		constexpr int APRON = EMBED != 0 ? kApron + 1 : kApron;
+		const int range = chunk >= a.first2 ? 1 : 0;
+		const int j0 = a.r_begin[range] + (chunk - (range ? a.first2 : 0)) * a.chunk;
+		const int j1 = (j0 + a.chunk < a.r_end[range]) ? j0 + a.chunk : a.r_end[range];
+		const int lo = a.js + j0 - APRON, hi1 = a.js + j1 + APRON;  // (lo > -ny and hi1 < 3 ny: a slab is at most the grid, ghost rows at most a slab)
+		const bool touches = (lo <= 0 && 0 <= hi1) || (lo <= a.ny && a.ny <= hi1) || (lo <= 2 * a.ny && 2 * a.ny <= hi1);
+		if (touches) fused_item<Real, MODEL, true, EMBED, COLS, NT>(s, a, strip, chunk);
+		else fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
+	} else {
+		fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
 	}
 }
 
@@ -517,15 +515,6 @@ __global__ void __launch_bounds__(256) crd_sum_partials_kernel(const double *__r
 	}
 	if (threadIdx.x == 0) *out = part[0];
 }
-
-// Tuning knobs (tools/tune_fused.py, tools/ring_ab.py flip them between launches of one process).  They are honoured only
-// when CRD_TUNING is set in the environment at the first launch; a production process never reads them.
-bool tuning_enabled()
-{
-	static const bool enabled = std::getenv("CRD_TUNING") != nullptr;
-	return enabled;
-}
-const char *tuning_knob(const char *name) { return tuning_enabled() ? std::getenv(name) : nullptr; }
 
 // Rows per work item.  Every item pays 8 apron rows, which argues for long chunks; but the wavefronts of a launch run in
 // "rounds" of (resident wavefront slots) items, a partly filled last round idles most of the chip, unequal wavefront
@@ -583,14 +572,14 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols)  // 0: 32 
 	// 7.3 -> 6.4 us per step; the reference's 100 x 400 Goldbeter grid: 8.2 -> 6.5).  With more blocks than that the extra apron rows
 	// cost more than they bring (512^2: 8.9 -> 9.8 us, 400 x 1600: 11.1 -> 12.9; the edge bands of a ring share: no change).
 	if (chunk == 8 && (long)((nstrips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + 7) / 8) < device_cus() / 2) chunk = 4;
-	if (const char *e = tuning_knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
+	if (const char *e = tuning::knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
 	if (chunk_mode == 2 && chunk == 32 && (long)nstrips * ((rows + 63) / 64) >= 2L * slots) chunk = 64;  // fewer apron rows recomputed: pays where fp64 issue binds (Goldbeter)
 	if (one_round) {
 		const long strip_blocks = (nstrips + kWavesPerBlock - 1) / kWavesPerBlock, fit = (slots / kWavesPerBlock) / strip_blocks;
 		const long need = fit >= 1 ? (rows + fit - 1) / fit : 0;
 		if (need > chunk && need <= 96) chunk = (int)need;
 	}
-	if (const char *e = tuning_knob("CRD_FUSED_CHUNK")) {  // tuning knob
+	if (const char *e = tuning::knob("CRD_FUSED_CHUNK")) {  // tuning knob
 		const int v = std::atoi(e);
 		if (v >= 1) chunk = v;
 	}
@@ -615,10 +604,14 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols)  // 0: 32 
 struct PlanCandidate {
 	int one_round, remap, cols, nt;  // one_round: the chunk mode -- 0 = 32 rows, 1 = stretched to one round, 2 = 64 rows
 };
-constexpr PlanCandidate kPlanCandidates[] = {{0, 0, 1, 0}, {0, 1, 1, 0}, {0, 2, 1, 0}, {1, 0, 1, 0}, {1, 1, 1, 0}, {2, 0, 1, 0}, {2, 1, 1, 0},
-                                             {0, 0, 2, 0}, {0, 1, 2, 0}, {0, 2, 2, 0}, {1, 0, 2, 0}, {1, 1, 2, 0}, {2, 0, 2, 0},
-                                             {0, 0, 1, 1}, {0, 1, 1, 1}, {0, 2, 1, 1}, {1, 0, 1, 1}, {1, 1, 1, 1}, {2, 0, 1, 1},
-                                             {0, 0, 2, 1}, {0, 1, 2, 1}, {0, 2, 2, 1}, {1, 0, 2, 1}, {1, 1, 2, 1}, {2, 0, 2, 1}};
+// (round 4: 64-row chunks also under mappings 1 / 2 and with two columns per lane -- where fp64 issue binds, Goldbeter, the recompute
+// factor of the apron rows is what is left to cut: (64 + 8) / 64 x 128 / 120 = 1.20 against (32 + 8) / 32 x 64 / 56 = 1.43)
+constexpr PlanCandidate kPlanCandidates[] = {
+    {0, 0, 1, 0}, {0, 1, 1, 0}, {0, 2, 1, 0}, {1, 0, 1, 0}, {1, 1, 1, 0}, {2, 0, 1, 0}, {2, 1, 1, 0}, {2, 2, 1, 0},
+    {0, 0, 2, 0}, {0, 1, 2, 0}, {0, 2, 2, 0}, {1, 0, 2, 0}, {1, 1, 2, 0}, {2, 0, 2, 0}, {2, 1, 2, 0}, {2, 2, 2, 0},
+    {0, 0, 1, 1}, {0, 1, 1, 1}, {0, 2, 1, 1}, {1, 0, 1, 1}, {1, 1, 1, 1}, {2, 0, 1, 1}, {2, 1, 1, 1}, {2, 2, 1, 1},
+    {0, 0, 2, 1}, {0, 1, 2, 1}, {0, 2, 2, 1}, {1, 0, 2, 1}, {1, 1, 2, 1}, {2, 0, 2, 1}, {2, 1, 2, 1}, {2, 2, 2, 1}};
+constexpr int kNumPlanCandidates = (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]);
 
 template <typename Real, int MODEL>
 hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, int js, int ny,
@@ -645,22 +638,14 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
 	// two columns per lane need an even nx (a pair must not straddle the periodic seam; rows then are 8- / 16-byte aligned too)
 	const bool cols2_ok = !c.embed && d.nx % 2 == 0;
-	// (where nothing has been measured: the packed arithmetic for fp32, one column for fp64)
+	// (where nothing has been measured: the packed arithmetic for fp32, one column for fp64 -- fused_default_columns)
 	int cols_default = (cols2_ok && sizeof(Real) == 4) ? 2 : 1;
-	if (const char *e = tuning_knob("CRD_FUSED_COLS")) cols_default = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;  // tuning knob
-	// A merged last step of an exchange cycle: rows [0, nyl) as bands + interior (see FusedArgs)
-	const int band = c.band_rows;
-	const bool merged = band > 0;
-	if (merged && (rows2 != 0 || c.embed || rows < 4 * band || !c.flag || !c.flag_counter)) return hipErrorInvalidValue;
-	// ... or a launch ALL of whose blocks count themselves in and whose last one writes the flag (band_rows = 0 with a flag: the
-	// separate edge-band launch, releasing the exchange without an event record between it and the interior launch)
-	const bool signal_all = !merged && c.flag != nullptr;
-	if (signal_all && (c.embed || !c.flag_counter)) return hipErrorInvalidValue;
+	if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols_default = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
 	// Four adjacent strips per block marching in lockstep: 0.417 ms on 8192^2 fp64 against 0.441 without the barriers and
 	// 0.4205 with one barrier per four iterations (tools/tune_fused.py, interleaved in one process; fp32 0.219 vs 0.232,
 	// Goldbeter -- instruction-bound -- unchanged); 2 or 8 strips per block lose half of the gain, 3 / 5 / 6 more.
 	int sw = kWavesPerBlock;
-	if (const char *e = tuning_knob("CRD_FUSED_STRIPS")) {  // tuning knobs
+	if (const char *e = tuning::knob("CRD_FUSED_STRIPS")) {
 		const int v = std::atoi(e);
 		if (v >= 1 && v <= kMaxWavesPerBlock) sw = v;
 	}
@@ -677,72 +662,33 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	bool nt = false;
 	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0) {
 		nt = want_nt != 0;
-		if (const char *e = tuning_knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0;  // tuning knob
+		if (const char *e = tuning::knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0;
 		cols = (want_cols == 2 && cols2_ok) ? 2 : 1;
-		if (const char *e = tuning_knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;  // tuning knob
+		if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
 		const int valid = cols * kLanes - 2 * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
 		a.nstrips = (d.nx + valid - 1) / valid;
 		const int nsb = (a.nstrips + sw - 1) / sw;
-		int mapped_chunks;  // chunks the block -> item mapping applies to (all of them, or the interior of a merged launch)
-		a.flag_chunks = a.flag_blocks = 0;
-		a.flag_counter = nullptr;
-		a.flag = nullptr;
-		a.flag_value = 0;
-		if (merged) {
-			// bands: 8-row items (what the separate band launch of rounds 1-2 ended up with: short, so that they are done early);
-			// interior: the chunks an interior-only launch of this height would get
-			int cb = 8;
-			if (const char *e = tuning_knob("CRD_FUSED_BANDCHUNK")) cb = std::atoi(e) >= 1 ? std::atoi(e) : cb;  // tuning knob
-			const int nb = (band + cb - 1) / cb, inner = rows - 2 * band;
-			const int ci = fused_chunk_rows<Real, MODEL>(a.nstrips, inner, one_round, cols);
-			const int r0[3] = {row_begin, row_end - band, row_begin + band}, r1[3] = {row_begin + band, row_end, row_end - band}, rc[3] = {cb, cb, ci};
-			mapped_chunks = (inner + ci - 1) / ci;
-			const int first[3] = {0, nb, 2 * nb};
-			for (int k = 0; k < 3; k++) {
-				a.r_begin[k] = r0[k];
-				a.r_end[k] = r1[k];
-				a.r_chunk[k] = rc[k];
-				a.r_first[k] = first[k];
-			}
-			a.nchunks = 2 * nb + mapped_chunks;
-			a.flag_chunks = 2 * nb;
-			a.flag_blocks = nsb * a.flag_chunks;
-			a.flag_counter = c.flag_counter;
-			a.flag = c.flag;
-			a.flag_value = c.flag_value;
-		} else {
-			const int ch = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round, cols);
-			const int n1 = (rows + ch - 1) / ch, n2 = (rows2 + ch - 1) / ch;
-			mapped_chunks = a.nchunks = n1 + n2;
-			const int r0[3] = {row_begin, row_begin2, 0}, r1[3] = {row_end, row_end2, 0}, first[3] = {0, n2 > 0 ? n1 : a.nchunks, a.nchunks};
-			for (int k = 0; k < 3; k++) {
-				a.r_begin[k] = r0[k];
-				a.r_end[k] = r1[k];
-				a.r_chunk[k] = ch;
-				a.r_first[k] = first[k];
-			}
-			if (signal_all) {
-				remap = 0;  // (every block is a "band" block: dispatch order)
-				a.flag_chunks = a.nchunks;
-				a.flag_blocks = nsb * a.nchunks;
-				a.flag_counter = c.flag_counter;
-				a.flag = c.flag;
-				a.flag_value = c.flag_value;
-			}
-		}
+		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round, cols);
+		const int n1 = (rows + a.chunk - 1) / a.chunk, n2 = (rows2 + a.chunk - 1) / a.chunk;
+		a.nchunks = n1 + n2;
+		a.first2 = n2 > 0 ? n1 : a.nchunks;
+		a.r_begin[0] = row_begin;
+		a.r_end[0] = row_end;
+		a.r_begin[1] = row_begin2;
+		a.r_end[1] = row_end2;
 		a.nitems = a.nstrips * a.nchunks;
 		a.nblocks = nsb * a.nchunks;
 		a.remap = remap;
-		if (const char *e = tuning_knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);  // tuning knob
+		if (const char *e = tuning::knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);
 		a.xs_lanes = 1;
 		if (a.remap == 2) {
 			const int per_xcd = resident_wavefronts<Real, MODEL>(cols) / sw / kNumXcd;
-			if (rows2 > 0 || mapped_chunks < 2 * kNumXcd || per_xcd < nsb) {
+			if (rows2 > 0 || a.nchunks < 2 * kNumXcd || per_xcd < nsb) {
 				a.remap = 0;  // two row ranges, or too few chunks / slots for lanes: plain order
 			} else {
 				a.xs_lanes = per_xcd / nsb;
-				const int most = (mapped_chunks + kNumXcd - 1) / kNumXcd;  // chunks of the best-served XCD
-				a.nblocks = a.flag_blocks + kNumXcd * ((most + a.xs_lanes - 1) / a.xs_lanes) * nsb * a.xs_lanes;
+				const int most = (a.nchunks + kNumXcd - 1) / kNumXcd;  // chunks of the best-served XCD
+				a.nblocks = kNumXcd * ((most + a.xs_lanes - 1) / a.xs_lanes) * nsb * a.xs_lanes;
 			}
 		}
 	};
@@ -787,8 +733,8 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	// Launch plan: measured once per context on the first full-size launch (a launch reads one plane set and writes another, so
 	// repeating it is harmless: every candidate writes the same values), then reused for every launch of similar height.
 	FusedPlan *plan = c.plan;
-	const bool plannable = plan && rows2 == 0 && (long)rows * d.nx >= (1L << 20) && !tuning_enabled();  // (under CRD_TUNING the knobs decide)
-	if (plannable && !merged && !plan->tuned && plan->autotune) {
+	const bool plannable = plan && rows2 == 0 && (long)rows * d.nx >= (1L << 20) && !tuning::enabled();  // (under CRD_TUNING the knobs decide)
+	if (plannable && !plan->tuned && plan->autotune) {
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		// (nothing else may run on the device while candidates are timed: a halo exchange still in flight on the second stream
 		// made a ring context pick a different -- worse -- plan than a plain slab of the same shape)
@@ -822,14 +768,14 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		// Candidates are timed round-robin, kRounds times, and each keeps its best round: a device's clock drifts while the
 		// measurement runs (a Goldbeter launch sequence lost 15 % over five candidates timed one after the other), and a
 		// candidate must not win or lose by its place in the queue.
-		constexpr int kCandidates = (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]), kRounds = 3;
+		constexpr int kCandidates = kNumPlanCandidates, kRounds = 3;
 		float t_best[kCandidates];
 		bool live[kCandidates];
 		int reps = 3;
 		for (int k = 0; k < kCandidates; k++) {
 			t_best[k] = 0.f;
 			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt);
-			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.r_chunk[0] == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols));  // (same as a 32-row plan)
+			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols));  // (same as a 32-row plan)
 			if (live[k] && kPlanCandidates[k].remap != a.remap) live[k] = false;  // (the mapping fell back to dispatch order)
 			if (live[k] && kPlanCandidates[k].cols != cols) live[k] = false;      // (two columns per lane not possible here, or pinned by a knob)
 			if (live[k] && (kPlanCandidates[k].nt != 0) != nt) live[k] = false;   // (pinned by a knob)
@@ -851,9 +797,9 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				}
 				if (err != hipSuccess) break;
 				ms /= (float)reps;
-				if (std::getenv("CRD_AUTOTUNE_VERBOSE"))
+				if ((plan->autotune >= 2 || tuning::verbose()))
 					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores: %.4f ms per launch (%d launches timed)\n",
-					             d.nx, rows, round, kPlanCandidates[k].one_round, a.r_chunk[0], a.remap, cols, nt ? "non-temporal" : "plain", ms, reps);
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, nt ? "non-temporal" : "plain", ms, reps);
 				if (t_best[k] == 0.f || ms < t_best[k]) t_best[k] = ms;
 			}
 		// Final: with two dozen candidates a few per cent apart, the fastest of the short bursts above is as often the luckiest as
@@ -882,9 +828,9 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
 				if (err != hipSuccess) break;
 				ms /= (float)reps2;
-				if (std::getenv("CRD_AUTOTUNE_VERBOSE"))
+				if ((plan->autotune >= 2 || tuning::verbose()))
 					std::fprintf(stderr, "libcrd autotune: %d x %d rows, final %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores: %.4f ms per launch (%d launches timed)\n",
-					             d.nx, rows, round, kPlanCandidates[k].one_round, a.r_chunk[0], a.remap, cols, nt ? "non-temporal" : "plain", ms, reps2);
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, nt ? "non-temporal" : "plain", ms, reps2);
 				if (t_final[f] == 0.f || ms < t_final[f]) t_final[f] = ms;
 			}
 		int best_k = 0;
@@ -911,10 +857,14 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		plan->ms_default = base;
 		plan->ms_best = best_k ? best : base;
 	}
-	const bool use_plan = plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows;
-	// (launches the plan was not measured on -- edge bands, short ranges -- still take its columns per lane: that choice is about
-	// the kernel's arithmetic, not about the launch's shape; the store hint stays with the launches it was measured on)
-	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default, use_plan ? plan->nt : 0);
+	// A measured plan applies to the launches it was measured on (heights within a tenth of it: the sweeps of a deep-halo cycle are).
+	// Launches it was not measured on -- edge bands, short ranges -- still take its columns per lane: that choice is about the
+	// kernel's arithmetic, not about the launch's shape.  A PINNED plan (crd_set_launch_plan) is an instruction, not a measurement:
+	// every single-range launch of the context takes all of it, of whatever size (chunk mode and mapping fall back inside configure
+	// where the launch is too small for them), two-range launches its columns per lane and store hint.
+	const bool pinned = plan && plan->tuned && plan->pinned && !tuning::enabled();
+	const bool use_plan = (plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows) || (pinned && rows2 == 0);
+	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default, (use_plan || pinned) ? plan->nt : 0);
 	return fire();
 }
 
@@ -931,6 +881,20 @@ int fused_max_items(const SlabDesc &d)
 }
 
 const char *fused_kernel_name(int, int) { return "crd_rk4_fused_step_kernel"; }
+
+int fused_default_columns(int precision, int nx) { return (precision == CRD_PRECISION_F32 && nx % 2 == 0) ? 2 : 1; }
+
+int fused_plan_candidates() { return kNumPlanCandidates; }
+
+bool fused_plan_candidate(int index, int *chunk_mode, int *mapping, int *cols, int *nt)
+{
+	if (index < 0 || index >= kNumPlanCandidates) return false;
+	*chunk_mode = kPlanCandidates[index].one_round;
+	*mapping = kPlanCandidates[index].remap;
+	*cols = kPlanCandidates[index].cols;
+	*nt = kPlanCandidates[index].nt;
+	return true;
+}
 
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s)

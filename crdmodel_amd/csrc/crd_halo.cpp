@@ -97,7 +97,7 @@ int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, 
 {
 	// Several issuing threads (one per device of a LOCAL group): every thread has enqueued the records of its contexts'
 	// edge events before any thread makes a stream wait for a neighbour's.
-	TraceRange range(depth == kGhost ? "crd_halo_exchange(deep)" : "crd_halo_exchange");
+	TraceRange range(depth > kStepHalo + 1 ? "crd_halo_exchange(deep)" : "crd_halo_exchange");
 	GroupBarrier *bar = cs[0]->bar;
 	if (bar && !bar->wait()) return fail(cs[0], CRD_ESTATE, "another slab's issuing thread failed");
 	// comm streams wait for the producers of the edge rows
@@ -111,13 +111,7 @@ int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, 
 			HIP_TRY(c, hipStreamWaitEvent(c->comm, prev->ev_edges, 0));
 			HIP_TRY(c, hipStreamWaitEvent(c->comm, next->ev_edges, 0));
 		}
-		if (c->flag_pending) {
-			// the edge bands are the first blocks of the launch just enqueued: the kernel itself says when they are in memory
-			HIP_TRY(c, hipStreamWaitValue64(c->comm, c->flag_dev, c->flag_epoch, hipStreamWaitValueGte, ~0ull));
-			c->flag_pending = false;
-		} else {
-			HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_edges, 0));
-		}
+		HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_edges, 0));
 	}
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
@@ -125,8 +119,6 @@ int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, 
 		int rc = (c->halo == CRD_HALO_RCCL) ? exchange_rccl(c, c->planes(plane_index), depth, with_v) : exchange_local_pull(c, plane_index, depth, with_v);
 		if (rc) return rc;
 		HIP_TRY(c, hipEventRecord(c->ev_halo, c->comm));
-		if (c->halo == CRD_HALO_RCCL && c->flag_mode > 0 && (c->flag_mode & 2))  // ... and, for the one-launch stepper's wait, as a value in signal memory
-			HIP_TRY(c, hipStreamWriteValue64(c->comm, c->halo_flag_dev, ++c->halo_epoch, 0));
 	}
 	// ... and every halo event is on record before any thread makes a stream wait for a neighbour's
 	if (bar && !bar->wait()) return fail(cs[0], CRD_ESTATE, "another slab's issuing thread failed");
@@ -192,7 +184,6 @@ int prime_halo(crd_ctx *const *cs, int n, int plane_index, int depth, bool with_
 	for (int k = 0; k < n; k++) {
 		if (int rc = set_device(cs[k])) return rc;
 		HIP_TRY(cs[k], hipEventRecord(cs[k]->ev_edges, cs[k]->compute));
-		HIP_TRY(cs[k], hipEventRecord(cs[k]->ev_interior, cs[k]->compute));
 	}
 	return exchange_stage_input(cs, n, plane_index, depth, with_v);
 }

@@ -175,7 +175,7 @@ int crd_halo_plan(int slab, int n_slabs, int64_t nyl, int depth, crd_halo_op ops
 
 int crd_cycle_vote(int pos, double vote[2])
 {
-	if (!vote || pos < -1 || pos >= kExchangeEvery) return CRD_EINVAL;
+	if (!vote || pos < -1 || pos >= kMaxExchangeEvery) return CRD_EINVAL;
 	vote[0] = (double)pos;  // element-wise MIN over the ranks: min(pos) and -max(pos)
 	vote[1] = -(double)pos;
 	return CRD_OK;
@@ -185,7 +185,7 @@ int crd_cycle_agreed(const double reduced[2])
 {
 	if (!reduced) return -1;
 	const double lo = reduced[0], hi = -reduced[1];
-	return (lo == hi && lo >= 0.0 && lo < (double)kExchangeEvery && lo == (double)(int)lo) ? (int)lo : -1;
+	return (lo == hi && lo >= 0.0 && lo < (double)kMaxExchangeEvery && lo == (double)(int)lo) ? (int)lo : -1;
 }
 
 static double gb_residual_y(double Z, double Y)

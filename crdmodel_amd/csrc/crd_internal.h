@@ -23,16 +23,16 @@ constexpr double kFhnReactionRate = 10.0, kGoldbeterReactionRate = 400.0;
 
 // Rows one fused RK4 step consumes on each side of the rows it produces (one per stage).
 constexpr int kStepHalo = 4;
-// Fused steps between two halo exchanges of a multi-slab run: the exchange moves kStepHalo * kExchangeEvery ghost rows and
-// each slab recomputes the shrinking ghost region redundantly in between (communication-avoiding deep halo).  8 against 4:
-// 0.9-1.6 % faster on 1024- to 4096-row slabs of an 8192-column grid (alternating runs of two builds on a world-size-1 ring).
-#ifndef CRD_EXCHANGE_EVERY
-#define CRD_EXCHANGE_EVERY 8  // tuning builds override it with -DCRD_EXCHANGE_EVERY=n
-#endif
-constexpr int kExchangeEvery = CRD_EXCHANGE_EVERY;
-static_assert(kExchangeEvery >= 3, "the multi-slab fused stepper splits the first and the last step of a cycle");
-// Ghost rows kept above and below every slab plane.
-constexpr int kGhost = kStepHalo * kExchangeEvery;
+// Fused steps between two halo exchanges of a multi-slab run (the exchange period E): the exchange moves kStepHalo * E ghost rows
+// and each slab recomputes the shrinking ghost region redundantly in between (communication-avoiding deep halo).  A property of
+// the run, chosen at run time (crd_set_exchange_period; bench.py rehearses 8 and 16 on the machine at hand): 8 against 4 measured
+// 0.9-1.6 % faster on 1024- to 4096-row slabs of an 8192-column grid on a world-size-1 ring; 16 halves the fixed cost per step of
+// a cycle again (two small launches, two cross-stream waits) for 3 % more redundant rows on a 1024-row share.
+constexpr int kMinExchangeEvery = 3;  // the multi-slab fused stepper splits the first and the last step of a cycle
+constexpr int kDefaultExchangeEvery = 8;
+constexpr int kMaxExchangeEvery = 16;
+// Ghost rows kept above and below every slab plane: what the longest cycle exchanges.
+constexpr int kGhost = kStepHalo * kMaxExchangeEvery;
 
 // Host-side coefficient tables of the diffusion operator written as
 //   du = cA[i] (uE - uW) + cX (uE - 2 uC + uW) + cP[i] (uN - 2 uC + uS)

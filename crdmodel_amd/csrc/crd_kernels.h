@@ -62,8 +62,9 @@ const char *stage_kernel_name(int precision, int model);
 // How the one-launch step cuts a slab into work items and deals them to the XCDs (crd_fused.hip: kPlanCandidates), measured
 // on the first full-size launch of a context when autotune is set.  Every plan computes bit-identical results.
 struct FusedPlan {
-	int autotune = 1;
+	int autotune = 1;                      // 0: never measure; 1: measure on the first full-size launch; 2: ... and print every timing to stderr
 	int tuned = 0;
+	int pinned = 0;                        // set by crd_set_launch_plan / CRD_LAUNCH_PLAN: applies to launches of every size
 	int one_round = 0, remap = 0;
 	int cols = 1;                          // grid columns per lane (1 or 2)
 	int nt = 0;                            // the new state stored with the non-temporal hint
@@ -87,18 +88,14 @@ struct FusedCall {
 	// launch reading what the previous one wrote as real stepping does, instead of repeating y0 -> yout (whose input, never
 	// overwritten, stays in the 256 MB memory-side cache on slabs that fit: a one-GPU share of an 8-GPU run does).
 	Planes tune_scratch{nullptr, nullptr};
-	// The last step of a multi-slab exchange cycle as ONE launch (rows [0, nyl), no second range): the two edge bands of band_rows
-	// rows go first, and when they are in memory the kernel itself writes flag_value to *flag (signal memory a stream waits on
-	// with hipStreamWaitValue64); flag_counter: a zero-initialised device word the band blocks count themselves in with.
-	int band_rows = 0;
-	unsigned *flag_counter = nullptr;
-	unsigned long long *flag = nullptr;
-	unsigned long long flag_value = 0;
 };
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s);
 const char *fused_kernel_name(int precision, int model);
 bool fused_step_supported(int precision, const SlabDesc &d);
+int fused_default_columns(int precision, int nx);  // columns per lane of launches without a measured plan
+int fused_plan_candidates();                       // the plans the tuner times (crd_launch_plan_candidate)
+bool fused_plan_candidate(int index, int *chunk_mode, int *mapping, int *cols, int *nt);
 int fused_max_items(const SlabDesc &d);
 
 // Layout adaptors between the AoS boundary layout (host precision: f64 or device precision) and SoA planes.

@@ -110,67 +110,21 @@ int staged_step_blocks(crd_ctx *const *cs, int n, double t, double dt)
 	return CRD_OK;
 }
 
-// Fused stepper on several slabs: ONE exchange every kExchangeEvery steps, kGhost = 4 * kExchangeEvery ghost rows of both
-// fields.  Step q of a cycle (q = 0 right after an exchange) produces rows [-e, nyl + e) with e = 4 (kExchangeEvery-1-q):
-// the still-valid part of the ghost region is recomputed redundantly (same kernel, same inputs, so bit-identical to what
-// the owning slab computes) instead of being communicated.  The last step of a cycle (e = 0) is split
-//   band:    [wait previous step] edge bands [0, B) and [nyl-B, nyl) in one launch -> record edges
-//   comm:    wait edges -> exchange kGhost rows of u and v with the ring neighbours -> record halo
-//   compute: interior [B, nyl-B) (needs neither ghost rows nor the bands)         -> record interior
+// Fused stepper on several slabs: ONE exchange every E = exchange_every steps (crd_set_exchange_period; default 8), G = 4 E ghost
+// rows of both fields.  Step q of a cycle (q = 0 right after an exchange) produces rows [-e, nyl + e) with e = 4 (E-1-q): the
+// still-valid part of the ghost region is recomputed redundantly (same kernel, same inputs, so bit-identical to what the owning
+// slab computes) instead of being communicated.  The last step of a cycle (e = 0) is split
+//   compute: edge bands [0, B) and [nyl-B, nyl) in one small launch -> record edges        (B = max(32, G): every row the exchange sends)
+//   comm:    wait edges -> exchange G rows of u and v with the ring neighbours -> record halo
+//   compute: interior [B, nyl-B) (needs neither ghost rows nor the bands)
 // and so is the first step of the next cycle
 //   compute: rows [4, nyl-4), which read owned rows only, straight after the interior sweep
-//   compute: [wait halo] rows [-e, 4) and [nyl-4, nyl+e), the ones that read ghost rows, in one small launch (e = kGhost - 4)
-// so the exchange has two sweeps to hide under.  Per step that is 1 + 2 / kExchangeEvery launches and 1 / kExchangeEvery of an
-// RCCL group on the host, against 3 launches + 1 group for a per-step exchange.
-constexpr int kFusedBand = 32;
-static_assert(kFusedBand >= kGhost, "the edge bands must contain every row the exchange sends");
-
-// The edge-band stream exists only in contexts that step a multi-slab run with the fused stepper; it is created on first use.
-int ensure_band_stream(crd_ctx *c)
-{
-	if (c->band || !c->bands_on_own_stream) return CRD_OK;
-	if (!c->streams->band) {
-		int lo = 0, hi = 0;  // the band launch is tiny and on the critical path of the exchange: give it priority over the interior sweep
-		HIP_TRY(c, hipDeviceGetStreamPriorityRange(&lo, &hi));
-		HIP_TRY(c, hipStreamCreateWithPriority(&c->streams->band, hipStreamNonBlocking, hi));
-	}
-	c->band = c->streams->band;
-	return CRD_OK;
-}
-
-// Signal memory + counter of the flag-triggered exchange, on first use; flag_mode = 0 when the platform has none (or
-// CRD_FLAG_EXCHANGE=0 asks for the two-launch form): the caller then takes the event path.
-int ensure_flag(crd_ctx *c)
-{
-	if (c->flag_mode >= 0) return CRD_OK;
-	c->flag_mode = 0;
-	// bit 0: bands + interior as ONE launch, the bands' blocks release the exchange; bit 1: the exchange releases the compute stream
-	// through a stream-written value; bit 2: the separate band launch releases the exchange itself (no event record).
-	// All three are built, bit-exact (tests) and measured on the world-size-1 ring (profiles/r03/ring_flag_variants.md) -- and
-	// all three lose against the events of rounds 1-2 on this stack: every band block's release fence is a write-back of its
-	// XCD's whole L2 (the band launch takes 24 us instead of 10 + a 7 us event bubble), the one-launch form leaves the slots of
-	// the finished band blocks to a second round of interior blocks (83 us against 10 + 7 + 50), and the value wait is a one-thread
-	// spinning kernel of 5 us where the event wait is a 6 us bubble.  Hence off unless asked for.
-	int want = 0;
-	if (const char *e = std::getenv("CRD_FLAG_EXCHANGE")) want = std::atoi(e) & 7;
-	if (want == 0 || c->halo != CRD_HALO_RCCL) return CRD_OK;  // (LOCAL groups pull from their neighbours' planes and wait for THEIR bands too: events)
-	void *flag = nullptr, *halo_flag = nullptr, *counter = nullptr;
-	if (hipExtMallocWithFlags(&flag, sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess ||
-	    hipExtMallocWithFlags(&halo_flag, sizeof(unsigned long long), hipMallocSignalMemory) != hipSuccess || hipMalloc(&counter, sizeof(unsigned)) != hipSuccess) {
-		(void)hipGetLastError();
-		for (void *q : {flag, halo_flag, counter})
-			if (q) (void)hipFree(q);
-		return CRD_OK;
-	}
-	HIP_TRY(c, hipMemset(flag, 0, sizeof(unsigned long long)));
-	HIP_TRY(c, hipMemset(halo_flag, 0, sizeof(unsigned long long)));
-	HIP_TRY(c, hipMemset(counter, 0, sizeof(unsigned)));
-	c->flag_dev = static_cast<unsigned long long *>(flag);
-	c->halo_flag_dev = static_cast<unsigned long long *>(halo_flag);
-	c->flag_counter = static_cast<unsigned *>(counter);
-	c->flag_mode = want;
-	return CRD_OK;
-}
+//   compute: [wait halo] rows [-e, 4) and [nyl-4, nyl+e), the ones that read ghost rows, in one small launch (e = G - 4)
+// so the exchange has two sweeps to hide under (three with crd_set_halo_slack(ctx, 2)).  Per step that is 1 + 2 / E launches and
+// 1 / E of an RCCL group on the host, against 3 launches + 1 group for a per-step exchange.
+inline int cycle_steps(const crd_ctx *c) { return c->exchange_every; }
+inline int cycle_ghost(const crd_ctx *c) { return kStepHalo * c->exchange_every; }
+inline int cycle_band(const crd_ctx *c) { return std::max(32, cycle_ghost(c)); }
 
 // The compute stream's wait for the halo of the exchange just made (and, in a LOCAL group, for the neighbours to have pulled
 // theirs out of this context's planes), with the diagnostics' event pair around it.
@@ -179,9 +133,7 @@ int wait_for_halo(crd_ctx *c)
 	// (diagnostics: how long does the compute stream stand at this wait?  Zero when the exchange hid under the sweeps)
 	const bool diag = c->diag_active && 4 * c->diag_waits + 1 < (int)c->ev_diag.size();
 	if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits)], c->compute));
-	if (c->flag_mode > 0 && (c->flag_mode & 2) && c->halo_epoch > 0)
-		HIP_TRY(c, hipStreamWaitValue64(c->compute, c->halo_flag_dev, c->halo_epoch, hipStreamWaitValueGte, ~0ull));  // (written behind the exchange)
-	else HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
+	HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
 	if (diag) HIP_TRY(c, hipEventRecord(c->ev_diag[(size_t)(4 * c->diag_waits++ + 1)], c->compute));
 	if (c->halo == CRD_HALO_LOCAL) {
 		// LOCAL halos are PULLED by the neighbours from this context's planes: the next launch that overwrites those rows must not
@@ -194,8 +146,9 @@ int wait_for_halo(crd_ctx *c)
 
 int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, bool timed_step, bool last_step_of_call)
 {
-	const int ext = kStepHalo * (kExchangeEvery - 1 - q);
-	if (q < kExchangeEvery - 1) {
+	const int E = cycle_steps(cs[0]), G = cycle_ghost(cs[0]), B = cycle_band(cs[0]);
+	const int ext = kStepHalo * (E - 1 - q);
+	if (q < E - 1) {
 		for (int k = 0; k < n; k++) {
 			crd_ctx *c = cs[k];
 			if (int rc = set_device(c)) return rc;
@@ -207,30 +160,27 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 				// exchange sends from / the neighbours pull from, which nobody may overwrite before the exchange is through -- and
 				// only then the compute stream waits, finishes step 0 (the rows that read ghost rows) and step 1 (its edges).
 				const FusedCall call0 = make_fused_call(c, c->deferred_t, dt, dst, src);  // step 0 read this step's output plane and wrote its input plane
-				const int ext0 = kStepHalo * (kExchangeEvery - 1);
-				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kFusedBand, c->nyl - kFusedBand, 0, 0, c->compute));
+				const int ext0 = kStepHalo * (E - 1);
+				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, B, c->nyl - B, 0, 0, c->compute));
 				if (int rc = wait_for_halo(c)) return rc;
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call0, -ext0, kStepHalo, c->nyl - kStepHalo, c->nyl + ext0, c->compute));
-				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, kFusedBand, c->nyl - kFusedBand, c->nyl + ext, c->compute));
+				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, B, c->nyl - B, c->nyl + ext, c->compute));
 				c->ghost_deferred = false;
 				continue;
 			}
 			if (q > 0) {
+				// (nothing to record: the next step runs on the same stream)
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
 				if (timed) c->timed_rows = c->nyl + 2 * ext;  // what crd_dominant_kernel_rows reports for this launch
-				// (nothing to record: the next step runs on the same stream; only the band stream, when there is one, needs
-				// ev_interior, and it is recorded by the step in front of the cycle's last one -- see below)
-				if (c->bands_on_own_stream && q == kExchangeEvery - 2) HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
 				continue;
 			}
 			// First step after an exchange.  Output rows [kStepHalo, nyl - kStepHalo) read owned rows only, so they are launched
-			// as soon as the bands of the previous step are in: the exchange gets this sweep as extra time to land.
-			const bool split = c->nyl >= 4 * kFusedBand;
-			if (c->bands_on_own_stream) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));  // otherwise the bands ran on this very stream
+			// straight behind the interior sweep of the previous step: the exchange gets this sweep as extra time to land.
+			const bool split = c->nyl >= 4 * B;
 			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kStepHalo, c->nyl - kStepHalo, 0, 0, c->compute));
-			if (split && c->halo_slack >= 2 && !last_step_of_call && !c->bands_on_own_stream && kExchangeEvery > 3) {
+			if (split && c->halo_slack >= 2 && !last_step_of_call && E > 3) {
 				c->ghost_deferred = true;  // the wait and the rows that read ghost rows follow behind the NEXT step's owned-only rows
 				c->deferred_t = t;
 				continue;
@@ -239,63 +189,25 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 			// the rows that read ghost rows: [-ext, kStepHalo) and [nyl - kStepHalo, nyl + ext) in one launch
 			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, kStepHalo, c->nyl - kStepHalo, c->nyl + ext, c->compute));
 			else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
-			if (c->bands_on_own_stream && q == kExchangeEvery - 2) HIP_TRY(c, hipEventRecord(c->ev_interior, c->compute));
 		}
 		return CRD_OK;
 	}
+	// last step of the cycle: edge bands, exchange released behind them, interior under the exchange
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
-		FusedCall call = make_fused_call(c, t, dt, src, dst);
-		const bool split = c->nyl >= 4 * kFusedBand;
-		if (int rc = ensure_flag(c)) return rc;
-		if (split && (c->flag_mode & 1) && !c->bands_on_own_stream && kExchangeEvery > 1) {
-			// ONE launch: edge bands as its first blocks, interior behind them; the kernel releases the exchange (flag)
-			call.band_rows = kFusedBand;
-			call.flag = c->flag_dev;
-			call.flag_counter = c->flag_counter;
-			call.flag_value = ++c->flag_epoch;
-			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
-			c->flag_pending = c->merged_step = true;
-			continue;
-		}
-		c->merged_step = false;
-		if (int rc = ensure_band_stream(c)) return rc;
-		hipStream_t bs = c->bands_on_own_stream ? c->band : c->compute;
-		if (kExchangeEvery == 1) {  // per-step exchange: this step's inputs were produced by the previous split step
-			HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_edges, 0));
-			HIP_TRY(c, hipStreamWaitEvent(bs, c->ev_halo, 0));
-		}
-		// previous step done (its output is read, its input plane is overwritten): stream order, unless the bands have a stream of their own
-		if (c->bands_on_own_stream) HIP_TRY(c, hipStreamWaitEvent(bs, c->ev_interior, 0));
-		// The band launch says itself when its rows are in memory (its last block writes the flag the exchange waits for): no event
-		// record between it and the interior launch, which cost the compute stream a ~6.5 us bubble per cycle.
-		const bool band_signals = split && c->flag_mode > 0 && (c->flag_mode & 4) && !c->bands_on_own_stream && kExchangeEvery > 1;
-		if (band_signals) {
-			call.flag = c->flag_dev;
-			call.flag_counter = c->flag_counter;
-			call.flag_value = ++c->flag_epoch;
-		}
-		if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, kFusedBand, c->nyl - kFusedBand, c->nyl, bs));
-		else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, bs));
-		if (band_signals) {
-			c->flag_pending = true;
-			call.flag = nullptr;
-			call.flag_counter = nullptr;
-		} else {
-			HIP_TRY(c, hipEventRecord(c->ev_edges, bs));
-		}
+		const FusedCall call = make_fused_call(c, t, dt, src, dst);
+		if (c->nyl >= 4 * B) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, B, c->nyl - B, c->nyl, c->compute));
+		else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
+		HIP_TRY(c, hipEventRecord(c->ev_edges, c->compute));
 	}
-	bool merged[64] = {};  // (contexts whose step went out as one launch above: exchange_stage_input clears their flag_pending)
-	for (int k = 0; k < n && k < 64; k++) merged[k] = cs[k]->flag_pending && cs[k]->merged_step;
-	if (int rc = exchange_stage_input(cs, n, dst, kGhost, true)) return rc;
+	if (int rc = exchange_stage_input(cs, n, dst, G, true)) return rc;
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
-		if (k < 64 && merged[k]) continue;
-		if (c->nyl >= 4 * kFusedBand) {
+		if (c->nyl >= 4 * B) {
 			const FusedCall call = make_fused_call(c, t, dt, src, dst);
-			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kFusedBand, c->nyl - kFusedBand, 0, 0, c->compute));
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, B, c->nyl - B, 0, 0, c->compute));
 		}
 	}
 	return CRD_OK;
@@ -328,7 +240,7 @@ int finish_cycle_agreement(crd_ctx *c, int *agreed)
 
 constexpr int kMaxTimedLaunches = 64;
 // Step of an exchange cycle whose single full-slab launch is the one timed in a multi-slab fused run (step 0 is split in two).
-constexpr int kTimedCycleStep = (kExchangeEvery > 2) ? 1 : 0;
+constexpr int kTimedCycleStep = 1;
 
 int ensure_timing_events(crd_ctx *c)
 {
@@ -424,6 +336,9 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		}
 	} else {
 		const bool fused = (stepper == CRD_STEPPER_FUSED);
+		const int E = cycle_steps(lead);
+		for (int k = 0; k < n; k++)
+			if (cs[k]->exchange_every != E) return fail(lead, CRD_EINVAL, "contexts of one run disagree on the exchange period");
 		// Where in the exchange cycle does the resident state stand?  If the previous call left it mid-cycle (or right after an
 		// exchange) the ghost rows are as good as they need to be and this call carries on from there; otherwise -- new state,
 		// staged stepper, slabs that disagree -- it starts with an exchange.  (A 20-step call on an 8192 x 1024 slab is 1.2 ms:
@@ -442,24 +357,24 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			if (ring) {
 				if (int rc = begin_cycle_agreement(lead, q0)) return rc;
 				agreement_pending = true;
-				if (q0 < 0 || q0 == kExchangeEvery - 1) {  // nothing to issue ahead of the answer
+				if (q0 < 0 || q0 == E - 1) {  // nothing to issue ahead of the answer
 					if (int rc = finish_cycle_agreement(lead, &q0)) return rc;
 					agreement_pending = false;
 				}
 			}
 			if (q0 < 0) {
 				if (ring && lead->cycle_start >= 0) lead->agreement_restarts++;
-				if (int rc = prime_halo(cs, n, crd_ctx::Y, fused ? kGhost : 1, fused)) return rc;
+				if (int rc = prime_halo(cs, n, crd_ctx::Y, fused ? cycle_ghost(lead) : 1, fused)) return rc;
 				q0 = 0;
 			}
 		}
 		int cur = crd_ctx::Y;
 		for (int64_t s = 0; s < nsteps; s++) {
-			const int q = (int)((s + q0) % kExchangeEvery);
+			const int q = (int)((s + q0) % E);
 			// time one launch of the dominant kernel mid-run (fused: the first one-launch step of a cycle)
 			// (fused: a step of the cycle that is one full-height launch, i.e. neither the split first nor the split last one)
 			const bool timed_step = timed_launches && !timed &&
-			                        (fused ? (q >= (lead->halo_slack >= 2 ? 2 : 1) && q <= kExchangeEvery - 2 && (s >= nsteps / 2 || s + kExchangeEvery >= nsteps)) : s >= nsteps / 2);
+			                        (fused ? (q >= (lead->halo_slack >= 2 ? 2 : 1) && q <= E - 2 && (s >= nsteps / 2 || s + E >= nsteps)) : s >= nsteps / 2);
 			const double t = t0 + (double)s * dt;
 			if (fused) {
 				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
@@ -478,7 +393,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 					// is untouched) and is overwritten by the one issued again below, in stream order.
 					lead->agreement_restarts++;
 					for (int k = 0; k < n; k++) cs[k]->ghost_deferred = false;  // (the step issued ahead of the answer is void, and so is what it deferred)
-					if (int rc = prime_halo(cs, n, crd_ctx::Y, kGhost, true)) return rc;
+					if (int rc = prime_halo(cs, n, crd_ctx::Y, cycle_ghost(lead), true)) return rc;
 					q0 = 0;
 					cur = crd_ctx::Y;
 					timed = 0;
@@ -500,7 +415,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			HIP_TRY(cs[k], hipStreamWaitEvent(cs[k]->compute, cs[k]->ev_halo, 0));
 		}
 		if (fused && nsteps > 0)
-			for (int k = 0; k < n; k++) cs[k]->cycle_pos = (int)((q0 + nsteps) % kExchangeEvery);
+			for (int k = 0; k < n; k++) cs[k]->cycle_pos = (int)((q0 + nsteps) % E);
 	}
 	if (timed_launches) *timed_launches = timed;
 	return CRD_OK;
@@ -539,8 +454,8 @@ int crd_step_rk4(crd_ctx *c, double t0, double dt, int64_t nsteps)
 // LOCAL groups spread over several devices get one issuing thread per device: a single thread that enqueues every launch, event
 // and peer copy of every GPU becomes the bottleneck once a GPU's share of a step is short (an 8192 x 1024 slab steps in ~60 us,
 // a thread needs a good part of that to issue one GPU's work).  The threads run the same step loop on their own contexts and meet
-// at the group's rendezvous around every halo exchange.  CRD_GROUP_THREADS=k forces k threads (also on one device: a test knob),
-// CRD_GROUP_THREADS=1 the single-thread path.
+// at the group's rendezvous around every halo exchange.  crd_group_set_threads(ctxs, n, k) forces k threads (also on one device:
+// how the tests exercise the rendezvous on a one-GPU box), k = 1 the single-thread path.
 int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps)
 {
 	if (int rc = check_group(ctxs, n)) return rc;
@@ -549,8 +464,7 @@ int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_
 			if (ctxs[k]->halo != CRD_HALO_LOCAL) return fail(ctxs[0], CRD_ESTATE, "group is not attached");
 	// contiguous runs of slabs per thread: by device, or by the knob
 	std::vector<int> first{0};
-	int forced = 0;
-	if (const char *e = std::getenv("CRD_GROUP_THREADS")) forced = std::atoi(e);
+	const int forced = ctxs[0]->group_threads;  // crd_group_set_threads: 0 = one per device
 	if (forced > 1) {
 		const int t = std::min(forced, n);
 		for (int q = 1; q < t; q++) first.push_back((int)((long)n * q / t));
@@ -780,6 +694,16 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	bool resume = dense && t0 == lead->dense.t_out && (!arkode_method || lead->ark.live);
 	for (int k = 0; k < n; k++)  // (every slab of a group must still hold the step: an upload to one of them alone ends the carry-over for all)
 		resume = resume && cs[k]->dense.pending && cs[k]->dense.t_out == lead->dense.t_out && cs[k]->dense.t_np1 == lead->dense.t_np1;
+	// Under RCCL that decision has to be the RING's (round-3 advice): crd_state_upload on one rank only is allowed between calls, and a
+	// rank that alone started afresh would run arkHin's exchanges and reductions while its neighbours skip them -- the ring's
+	// collectives would no longer pair.  One ncclAllReduce(min) of the ranks' votes: every rank resumes, or none does.
+	if (lead->halo == CRD_HALO_RCCL && n == 1) {
+		int all = 0;
+		if (int rc = begin_cycle_agreement(lead, resume ? 0 : -1)) return rc;
+		if (int rc = finish_cycle_agreement(lead, &all)) return rc;
+		if (resume && all != 0) lead->agreement_restarts++;
+		resume = resume && all == 0;
+	}
 	for (int k = 0; k < n; k++)
 		if (!resume) cs[k]->dense.pending = false;
 	auto hand_back = [&](double theta, double hstep) -> int {  // interpolant of step prev -> cur at t_prev + theta hstep into plane Y, planes re-labelled
@@ -1047,6 +971,25 @@ int crd_plan_launches(crd_ctx *c)
 	return CRD_OK;
 }
 
+int crd_group_set_threads(crd_ctx *const *ctxs, int n, int threads)
+{
+	if (int rc = check_group(ctxs, n)) return rc;
+	if (threads < 0) return fail(ctxs[0], CRD_EINVAL, "issuing threads: 0 = one per device, k >= 1 = exactly k");
+	ctxs[0]->group_threads = threads;
+	return CRD_OK;
+}
+
+int crd_set_exchange_period(crd_ctx *c, int steps)
+{
+	if (!c) return CRD_EINVAL;
+	if (steps < kMinExchangeEvery || steps > kMaxExchangeEvery) return fail(c, CRD_EINVAL, "exchange period: 3 .. 16 steps");
+	if (c->exchange_every != steps) c->cycle_pos = -1;  // the ghost rows were exchanged for another cycle length
+	c->exchange_every = steps;
+	return CRD_OK;
+}
+
+int crd_get_exchange_period(const crd_ctx *c) { return c ? c->exchange_every : CRD_EINVAL; }
+
 int crd_set_halo_slack(crd_ctx *c, int sweeps)
 {
 	if (!c) return CRD_EINVAL;
@@ -1136,7 +1079,7 @@ int crd_dominant_kernel_rows(const crd_ctx *c, int64_t *rows)
 	const int stepper = resolve_stepper(c);
 	if (c->halo == CRD_HALO_SELF) *rows = c->nyl;
 	else if (stepper == CRD_STEPPER_FUSED)  // the launch crd_step_rk4_timed last timed (before any: the second step of an exchange cycle)
-		*rows = c->timed_rows > 0 ? c->timed_rows : c->nyl + 2 * kStepHalo * (kExchangeEvery - 1 - kTimedCycleStep);
+		*rows = c->timed_rows > 0 ? c->timed_rows : c->nyl + 2 * kStepHalo * (c->exchange_every - 1 - kTimedCycleStep);
 	else *rows = c->nyl - 2;
 	return CRD_OK;
 }

@@ -13,22 +13,20 @@ namespace crd {
 
 namespace {
 
+// Bound once, by whichever thread traces first (crd_run's writer thread and its stepping thread may both be that thread, so may
+// two issuing threads of a LOCAL group): std::call_once orders the binding before every reader of the two pointers.
 struct Roctx {
 	int (*push)(const char *) = nullptr;
 	int (*pop)() = nullptr;
-	bool tried = false;
 };
 Roctx g_roctx;
+std::once_flag g_roctx_once;
 
-bool bind_roctx()
+void bind_roctx()
 {
-	static std::mutex once;
-	std::lock_guard<std::mutex> lock(once);
-	if (g_roctx.tried) return g_roctx.push != nullptr;
-	g_roctx.tried = true;
 	const char *force = std::getenv("CRD_ROCTX");
 	const bool wanted = force ? std::atoi(force) != 0 : std::getenv("ROCP_TOOL_LIBRARIES") != nullptr;
-	if (!wanted) return false;
+	if (!wanted) return;
 	// rocprofv3 --marker-trace listens to the rocprofiler-sdk build of roctx; the roctracer one is the fallback for older tools
 	for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"}) {
 		void *h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -38,22 +36,23 @@ bool bind_roctx()
 		if (push && pop) {
 			g_roctx.push = push;
 			g_roctx.pop = pop;
-			return true;
+			return;
 		}
 	}
-	return false;
 }
 
 }  // namespace
 
 void trace_push(const char *name)
 {
-	if ((g_roctx.push || (!g_roctx.tried && bind_roctx())) && name) (void)g_roctx.push(name);
+	std::call_once(g_roctx_once, bind_roctx);
+	if (g_roctx.push && name) (void)g_roctx.push(name);
 }
 
 void trace_pop()
 {
-	if (g_roctx.push) (void)g_roctx.pop();
+	std::call_once(g_roctx_once, bind_roctx);
+	if (g_roctx.pop) (void)g_roctx.pop();
 }
 
 }  // namespace crd

@@ -293,6 +293,13 @@ class Slab:
         """1 or 2 sweeps of owned-only rows between an exchange and the wait for its halo (crd_set_halo_slack)."""
         self._check(lib().crd_set_halo_slack(self._h, sweeps), "crd_set_halo_slack")
 
+    def set_exchange_period(self, steps):
+        """Fused steps between two deep-halo exchanges (crd_set_exchange_period): 3 .. 16, the same on every slab / rank of a run."""
+        self._check(lib().crd_set_exchange_period(self._h, steps), "crd_set_exchange_period")
+
+    def exchange_period(self):
+        return lib().crd_get_exchange_period(self._h)
+
     def step_timing(self):
         """What the last step_rk4_timed call measured (crd_step_timing) as a dict."""
         tm = capi.StepTiming()
@@ -308,7 +315,8 @@ class Slab:
         return lib().crd_dominant_kernel_name(self._h).decode()
 
     def set_autotune(self, on):
-        self._check(lib().crd_set_autotune(self._h, 1 if on else 0), "crd_set_autotune")
+        """0 / False: never measure a launch plan; 1 / True: measure on the first full-size launch; 2: ... and print the timings."""
+        self._check(lib().crd_set_autotune(self._h, int(on)), "crd_set_autotune")
 
     def set_launch_plan(self, chunk_mode, xcd_mapping, columns_per_lane, nontemporal_stores=0):
         """Pin the launch plan of the fixed-step kernel (crd_set_launch_plan) instead of having it measured."""
@@ -366,6 +374,25 @@ class PinnedArray:
             self.close()
         except Exception:
             pass
+
+
+def launch_plan_candidates():
+    """The plans the launch-plan measurement chooses among, as (chunk_mode, xcd_mapping, columns_per_lane, nontemporal_stores)."""
+    out, k = [], 0
+    while True:
+        lp = capi.LaunchPlan()
+        if lib().crd_launch_plan_candidate(k, C.byref(lp)) != 0:
+            return out
+        out.append((lp.one_round, lp.xcd_mapping, lp.columns_per_lane, lp.nontemporal_stores))
+        k += 1
+
+
+def plan_key(model, precision, plan):
+    """Key of a launch plan in profiles/pmc_traffic.json / profiles/plan_stats.json: plan = (chunk_mode, mapping, columns, nt) or the
+    dict Slab.launch_plan() returns."""
+    if isinstance(plan, dict):
+        plan = (plan["one_round"], plan["xcd_mapping"], plan["columns_per_lane"], plan["nontemporal_stores"])
+    return "fused/%s/%s/chunk%d/map%d/cols%d/%s" % (model, precision, plan[0], plan[1], plan[2], "nt" if plan[3] else "plain")
 
 
 def rccl_unique_id():
@@ -426,6 +453,14 @@ class LocalGroup:
     def set_halo_slack(self, sweeps):
         for s in self.slabs:
             s.set_halo_slack(sweeps)
+
+    def set_exchange_period(self, steps):
+        for s in self.slabs:
+            s.set_exchange_period(steps)
+
+    def set_threads(self, threads):
+        """Host threads issuing the group's work in step_rk4 (crd_group_set_threads): 0 = one per device."""
+        check(lib().crd_group_set_threads(self._arr, len(self.slabs), threads), "crd_group_set_threads", self.slabs[0].handle)
 
     def integrate_adaptive(self, t0, tout, **options):
         opt, st = _adaptive_options(options), capi.AdaptiveStats()

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CRD_ABI_VERSION 3
+#define CRD_ABI_VERSION 4
 
 typedef enum crd_status {
 	CRD_OK = 0,
@@ -41,7 +41,7 @@ enum { CRD_PRECISION_F64 = 0, CRD_PRECISION_F32 = 1 };
 enum {
 	CRD_STEPPER_AUTO = 0,
 	CRD_STEPPER_STAGED = 1, /* four stage kernels per step, one halo row exchanged per stage */
-	CRD_STEPPER_FUSED = 2   /* one kernel per step (all four stages on chip); multi-slab: 32 halo rows every 8 steps; slabs shorter than that use the staged kernels */
+	CRD_STEPPER_FUSED = 2   /* one kernel per step (all four stages on chip); multi-slab: 4 E halo rows every E steps (crd_set_exchange_period, default 8); slabs shorter than that use the staged kernels */
 };
 
 /* Halo transport between the slabs of one run. */
@@ -224,12 +224,12 @@ int crd_comm_info(const crd_ctx *ctx, int *halo, int *ranks, int *rank);
 
 /* ONE halo exchange of the resident state, outside any step: fills ghost rows [-depth, 0) and [nyl, nyl+depth) of both
  * fields from the ring neighbours (the N/S half of Exchange(), src/FHNmodel_torus.cpp:775-950, at the depth the fused
- * stepper uses) and waits for it.  1 <= depth <= 32.  Every rank of an RCCL run must make the same call.  Together with
+ * stepper uses) and waits for it.  1 <= depth <= 64.  Every rank of an RCCL run must make the same call.  Together with
  * crd_state_download_rows it lets a host program verify the transport (ghost rows == the neighbours' owned rows). */
 int crd_halo_exchange(crd_ctx *ctx, int depth);
 
 /* Rows [row_begin, row_begin + row_count) of ONE field (var 0 / 1) of the resident state, ghost rows included
- * (-32 <= row_begin, row_begin + row_count <= nyl + 32), as contiguous rows of nx reals in the DEVICE precision. */
+ * (-64 <= row_begin, row_begin + row_count <= nyl + 64), as contiguous rows of nx reals in the DEVICE precision. */
 int crd_state_download_rows(crd_ctx *ctx, int var, int64_t row_begin, int64_t row_count, void *rows_host);
 
 /* The ring protocol of one halo exchange, as data: the four point-to-point operations slab `slab` of `n_slabs` issues,
@@ -249,7 +249,7 @@ int crd_halo_plan(int slab, int n_slabs, int64_t nyl, int depth, crd_halo_op ops
 
 /* How the ranks of an RCCL ring agree, at the start of a stepping call, where in the deep-halo exchange cycle the ring stands --
  * as data, like crd_halo_plan, so that the rule can be driven over any transport (the CPU tests use gloo).  Each rank votes
- * crd_cycle_vote(pos): pos = steps its resident state has taken since its ghost rows were last exchanged (0 .. 7), or -1 for a
+ * crd_cycle_vote(pos): pos = steps its resident state has taken since its ghost rows were last exchanged (0 .. E - 1), or -1 for a
  * state whose ghost rows cannot be trusted (new upload, other stepper, failed call).  The element-wise MIN of the votes over
  * the ranks (ncclAllReduce in the library) goes to crd_cycle_agreed: the common position when every rank voted the same
  * non-negative one -- the call carries on there -- else -1: every rank starts with an exchange.  No reference counterpart: the
@@ -288,6 +288,16 @@ int crd_rhs_device(crd_ctx *ctx, double t, const void *y_aos_dev, void *ydot_aos
  * call's first step except when that step is the one that exchanges. */
 int crd_set_stepper(crd_ctx *ctx, int stepper);
 int crd_step_rk4(crd_ctx *ctx, double t0, double dt, int64_t nsteps);
+
+/* The exchange period E of the one-launch stepper on several slabs: E steps between two halo exchanges, each of 4 E ghost rows
+ * of both fields; in between every slab recomputes the shrinking ghost region redundantly (same kernel, same inputs: bit-identical
+ * to what the owner computes).  3 <= E <= 16, default 8.  A property of the RUN: every context of a LOCAL group / every rank of a
+ * ring must be given the same value before its next stepping call (which then starts with an exchange).  A longer period halves the
+ * per-step share of a cycle's fixed cost (two small launches, two cross-stream waits) and of the exchange's latency for a few per
+ * cent more redundant rows; bench.py rehearses 8 and 16 on the machine at hand.  Slabs shorter than 4 E rows step with the staged
+ * kernels.  Replaces nothing in the reference: its Exchange() runs inside every f() (src/FHNmodel_torus.cpp:521). */
+int crd_set_exchange_period(crd_ctx *ctx, int steps);
+int crd_get_exchange_period(const crd_ctx *ctx);
 int crd_synchronize(crd_ctx *ctx);
 
 /* Error-controlled integration from t0 to exactly tout on the resident state: replaces what the reference gets from
@@ -355,6 +365,10 @@ int crd_group_integrate_adaptive(crd_ctx *const *ctxs, int n, double t0, double 
 /* LOCAL groups (several slabs driven by one host thread): the same two operations on every slab of the run in
  * lockstep; ctxs[k] must be slab k of n.  y[k] / ydot[k] are device pointers on ctxs[k]'s device. */
 int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps);
+/* Host threads that issue a group's work in crd_group_step_rk4: 0 (default) = one per device the group is spread over, k >= 1 =
+ * exactly k (contiguous runs of slabs per thread; k = 1: the calling thread alone).  The threads meet at a host rendezvous around
+ * every halo exchange; results do not depend on k. */
+int crd_group_set_threads(crd_ctx *const *ctxs, int n, int threads);
 int crd_group_rhs_device(crd_ctx *const *ctxs, int n, double t, const void *const *y_aos_dev, void *const *ydot_aos_dev);
 int crd_group_rhs_host(crd_ctx *const *ctxs, int n, double t, const void *const *y_aos, void *const *ydot_aos); /* host vectors, device precision */
 
@@ -404,11 +418,13 @@ const char *crd_dominant_kernel_name(const crd_ctx *ctx);
  * every workgroup is resident at once), how the items are dealt to the 8 XCDs, how many columns a lane steps and how the new
  * state is stored is measured on the device at hand, on the
  * context's first full-size step (a handful of extra launches of that step; every plan computes bit-identical results), unless
- * autotuning is off (crd_set_autotune(ctx, 0) or CRD_AUTOTUNE=0 in the environment: always the plain plan).  No reference
- * counterpart: a property of this implementation. */
+ * autotuning is off (crd_set_autotune(ctx, 0) or CRD_AUTOTUNE=0 in the environment): launches then take 32-row chunks in dispatch
+ * order, plain stores and the default columns per lane of their precision (fp32 on an even nx: two; crd_get_launch_plan reports
+ * it).  crd_set_autotune(ctx, 2) / CRD_AUTOTUNE=2 also prints every candidate's timing to stderr.  No reference counterpart: a
+ * property of this implementation. */
 typedef struct crd_launch_plan {
-	int32_t autotune;     /* measuring enabled */
-	int32_t tuned;        /* a measurement has been made */
+	int32_t autotune;     /* measuring enabled (2: verbose) */
+	int32_t tuned;        /* a measurement has been made (or a plan pinned) */
 	int32_t one_round;    /* chunk mode: 0 = 32-row chunks, 1 = stretched so that all workgroups are resident at once, 2 = 64-row chunks */
 	int32_t xcd_mapping;  /* 0 theta-first dispatch order, 1 one contiguous band of the slab per XCD, 2 the same with succession in phi */
 	int32_t rows;         /* height of the launch it was measured on */
@@ -421,11 +437,16 @@ typedef struct crd_launch_plan {
 } crd_launch_plan;
 int crd_set_autotune(crd_ctx *ctx, int on);
 int crd_get_launch_plan(const crd_ctx *ctx, crd_launch_plan *out);
+/* The plans the measurement chooses among, index 0 .. (first index that returns CRD_EINVAL) - 1: one_round, xcd_mapping,
+ * columns_per_lane and nontemporal_stores of *out are set, the rest zero.  (tools/plan_sweep.py profiles every one of them;
+ * tests/test_profiles.py checks that profiles/pmc_traffic.json has an entry for each.) */
+int crd_launch_plan_candidate(int index, crd_launch_plan *out);
 /* Use THIS plan (chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1) for the fixed-step kernel instead of measuring one -- a plan
  * read back from an earlier context of the same shape on the same device (the measurement costs ~0.45 s per context at 8192^2), or
- * a profiling run in which every launch of the kernel should be the plan a previous run chose (`bench.py --launch-plan`).  Where
- * a choice cannot be honoured (two columns per lane on an odd nx, mapping 2 on a launch too short for it) the launch falls back as
- * it would for a measured plan.  crd_get_launch_plan then reports tuned = 1 with both times 0.  CRD_EINVAL outside the ranges. */
+ * a profiling run in which every launch of the kernel should be the plan a previous run chose (`bench.py --launch-plan`).  A pinned
+ * plan applies to launches of EVERY size (a measured one only to launches of the height it was measured on).  Where a choice cannot
+ * be honoured (two columns per lane on an odd nx, mapping 2 on a launch too short for it) the launch falls back as it would for a
+ * measured plan.  crd_get_launch_plan then reports tuned = 1 with both times 0.  CRD_EINVAL outside the ranges. */
 int crd_set_launch_plan(crd_ctx *ctx, int chunk_mode, int xcd_mapping, int columns_per_lane, int nontemporal_stores);
 /* Measure the plan NOW (a step of the resident state into scratch planes, discarded; the state is not advanced) instead of
  * inside the first crd_step_rk4 -- for callers that time their first steps; also creates the events crd_step_rk4_timed uses.  The

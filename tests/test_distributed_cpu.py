@@ -25,18 +25,9 @@ def _free_port():
 
 def _exchange(dist, plane, nyl, depth, rank, world, crd):
     """Run the library's halo plan on a (nyl + 2 depth, nx) host plane with gloo point-to-point operations."""
-    import torch
+    from tests import standin_crd
 
-    ops, keep = [], []
-    for is_send, peer, row_begin, row_count in crd.halo_plan(rank, world, nyl, depth):
-        view = plane[depth + row_begin: depth + row_begin + row_count]
-        if peer == rank:  # self ring (world 1) is handled by the caller
-            raise AssertionError("self peer in a multi-rank run")
-        t = torch.from_numpy(view)
-        keep.append(t)
-        ops.append(dist.P2POp(dist.isend if is_send else dist.irecv, t, peer))
-    for req in dist.batch_isend_irecv(ops):
-        req.wait()
+    standin_crd.exchange(dist, plane, nyl, depth, rank, world)
 
 
 def _worker(rank, world, port, result_dir):
@@ -168,7 +159,7 @@ def _worker(rank, world, port, result_dir):
             dist.all_reduce(t, op=dist.ReduceOp.MIN)
             return crd.cycle_agreed(t.tolist())
 
-        for pos in range(8):
+        for pos in range(16):  # (positions of the longest exchange period, crd_set_exchange_period)
             assert ring_decision(pos) == pos
         assert ring_decision(-1) == -1
         assert ring_decision(-1 if rank == world - 1 else 5) == -1  # one rank uploaded a new state: every rank hears of it
@@ -176,7 +167,7 @@ def _worker(rank, world, port, result_dir):
         assert ring_decision(3 if rank == 0 else 4) == -1           # (cannot happen with collective stepping calls; still decided alike)
         assert ring_decision(7 if rank == 0 else 0) == -1
         with pytest.raises(crd._capi.CrdError):
-            crd.cycle_vote(8)
+            crd.cycle_vote(16)
         open(os.path.join(result_dir, "ok.%d" % rank), "w").write("ok")
     finally:
         dist.destroy_process_group()
@@ -208,103 +199,15 @@ def test_halo_plan_shape():
         crd.halo_plan(0, 2, 3, 4)
 
 
-class _StandInSlab:
-    """What bench.run needs of crdmodel_amd.Slab, with the planes in numpy and the halos moved by the library's own ring plan
-    over gloo.  NOT a compute path: stepping does nothing but count; this exists so that bench.py's N > 1 control flow runs
-    with real ranks before it ever meets more than one GPU."""
-
-    exposed_ms_by_rank = {}  # rank -> exposed halo wait per exchange the stand-in reports (to exercise the slack decision)
-
-    def __init__(self, crd, dist, params, rank, world, device):
-        self.crd, self.dist, self.params, self.slab, self.n_slabs = crd, dist, params, rank, world
-        self.grid = crd.grid_of(params)
-        self.js, self.je = crd.slab_extents(self.grid.ny, rank, world)
-        self.nx, self.nyl = self.grid.nx, self.je - self.js + 1
-        self.dtype = np.float64 if params.precision == 0 else np.float32
-        self.plane = np.zeros((2, self.nyl + 64, self.nx), dtype=self.dtype)
-        self.ring, self.diag, self.slack, self.steps, self.calls = False, False, 1, 0, []
-
-    def init_rccl(self, ident):
-        assert bytes(ident) == b"\x07" * 128, "the id every rank joins with is rank 0's"
-        self.ring = True
-
-    def set_stepper(self, stepper):
-        self.calls.append(("stepper", stepper))
-
-    def comm_info(self):
-        return ("rccl", self.n_slabs, self.slab) if self.ring else ("self", 1, 0)
-
-    def upload(self, y):
-        assert y.shape == (self.nyl, self.nx, 2)
-        self.plane[0, 32:32 + self.nyl], self.plane[1, 32:32 + self.nyl] = y[..., 0], y[..., 1]
-
-    def halo_exchange(self, depth):
-        for var in (0, 1):
-            view = np.ascontiguousarray(self.plane[var, 32 - depth:32 + self.nyl + depth])
-            _exchange(self.dist, view, self.nyl, depth, self.slab, self.n_slabs, self.crd)
-            self.plane[var, 32 - depth:32 + self.nyl + depth] = view
-
-    def download_rows(self, var, row_begin, row_count):
-        return self.plane[var, 32 + row_begin:32 + row_begin + row_count].copy()
-
-    def dominant_kernel(self):
-        return "crd_rk4_fused_step_kernel"
-
-    def dominant_kernel_rows(self):
-        return self.nyl + 48
-
-    def plan_launches(self):
-        self.calls.append(("plan",))
-
-    def launch_plan(self):
-        return {"autotune": 1, "tuned": 1, "one_round": 0, "xcd_mapping": 2, "rows": self.nyl, "columns_per_lane": 1, "nontemporal_stores": 0, "ms_default": 0.06, "ms_chosen": 0.058}
-
-    def step_rk4(self, t0, dt, nsteps, sync=True):
-        self.steps += nsteps
-
-    def step_rk4_timed(self, t0, dt, nsteps):
-        self.steps += nsteps
-        self.last_timed = nsteps
-        return 0.06 * nsteps, 0.055, 1
-
-    def set_diagnostics(self, on):
-        self.diag = bool(on)
-
-    def set_halo_slack(self, sweeps):
-        self.slack = sweeps
-
-    def step_timing(self):
-        n = max(1, self.last_timed // 8)
-        exposed = self.exposed_ms_by_rank.get(self.slab, 0.011) if self.slack == 1 else 0.012
-        return {"ms_total": 0.06 * self.last_timed, "kernel_ms": 0.055, "exposed_halo_ms": exposed * n, "exchange_ms": 0.09 * n, "steps": self.last_timed,
-                "halo_slack": self.slack, "halo_waits": n, "exchanges": n, "agreement_restarts": 0}
-
-    def max_abs(self):
-        return 2.0
-
-    def close(self):
-        self.calls.append(("close",))
-
-
 def _bench_worker(rank, world, port, result_dir, exposed_rank, size):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    import types
-
     import torch.distributed as dist
 
     import bench
-    import crdmodel_amd as crd
+    from tests import standin_crd as fake  # the stand-in for the device context (numpy planes, halos over gloo by the library's ring plan)
 
-    slabs = []
-
-    def make_slab(params, r, w, device):
-        slabs.append(_StandInSlab(crd, dist, params, r, w, device))
-        return slabs[-1]
-
-    _StandInSlab.exposed_ms_by_rank = {exposed_rank: 0.08} if exposed_rank >= 0 else {}
-    fake = types.SimpleNamespace(make_params=crd.make_params, stable_dt=crd.stable_dt, run_config=crd.run_config, initial_conditions=crd.initial_conditions,
-                                 rccl_unique_id=lambda: b"\x07" * 128, Slab=make_slab)
+    fake.exposed_ms_by_rank = {exposed_rank: 0.08} if exposed_rank >= 0 else {}
     lines = []
     args = bench.parse(["--gpus", str(world), "--size", str(size), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"])
     try:
@@ -317,6 +220,7 @@ def _bench_worker(rank, world, port, result_dir, exposed_rank, size):
         open(os.path.join(result_dir, "line.json"), "w").write(lines[0])
     else:
         assert not lines  # rank 0 alone prints
+    slabs = fake.created
     assert slabs[0].calls[-1] == ("close",) and slabs[0].slack == (2 if exposed_rank >= 0 else 1)
     open(os.path.join(result_dir, "ok.%d" % rank), "w").write("ok")
 
@@ -331,7 +235,7 @@ def test_bench_multi_rank_control_flow(tmp_path, world, exposed_rank):
     import torch.multiprocessing as mp
 
     port = _free_port()
-    size = 128 if world < 8 else 512  # a slab of the deep-halo cycle holds at least its 32 ghost rows
+    size = 128 if world < 8 else 512  # a slab of the deep-halo cycle holds at least its 32 ghost rows (none reaches the 256 the period rehearsal asks for)
     mp.spawn(_bench_worker, args=(world, port, str(tmp_path), exposed_rank, size), nprocs=world, join=True)
     assert sorted(f for f in os.listdir(tmp_path) if f.startswith("ok.")) == ["ok.%d" % r for r in range(world)]
     d = json.loads(open(os.path.join(tmp_path, "line.json")).read())
@@ -347,3 +251,55 @@ def test_bench_multi_rank_control_flow(tmp_path, world, exposed_rank):
     assert [r["rank"] for r in d["per_rank"]] == list(range(world))
     assert all(r["halo_slack"] == halo["slack"]["sweeps"] and r["exchanges"] == 3 and r["kernel_ms"] == 0.055 for r in d["per_rank"])
     assert d["roofline"]["kernel"] == "crd_rk4_fused_step_kernel" and d["roofline"]["bound"] == "hbm" and d["config"]["decomposition"] == "phi-slabs x%d" % world
+
+
+def _run_bench(argv, extra_env=None, timeout=240):
+    import subprocess
+
+    env = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), **(extra_env or {}))
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_launches_its_own_ranks(world):
+    """`python bench.py --gpus N` without a launcher (the form the driver uses; the reference's scripts say `mpirun -np 4`,
+    util/ShellScripts/runFHNmodelTorus.sh:6): bench.py starts its N rank processes itself -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
+    before it imports torch or touches a device --, rank 0's line comes back through the parent, one line on stdout, status 0.  Here
+    against the stand-in for the device context, 2 and 3 real processes over gloo; slabs of 300+ rows, so the exchange-period
+    rehearsal runs too (the stand-in reports 16 steps no faster than 8: 8 stays)."""
+    size = 320 * world
+    r = _run_bench(["--gpus", str(world), "--size", str(size), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--crd-module", "tests.standin_crd"],
+                   extra_env={"STANDIN_EXPOSED": "1:0.08"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == world and d["steps"] == 20 and d["warmup"] == 5 and d["config"]["halo"]["transport"] == "rccl"
+    assert d["config"]["launcher"]["transports_tried"] == ["rccl"] and d["config"]["launcher"]["fallback_reasons"] == []
+    assert d["config"]["halo"]["halo_selfcheck"]["ok"] and d["config"]["halo"]["slack"]["sweeps"] == 2
+    ep = d["config"]["halo"]["exchange_period"]
+    assert ep["steps"] == 8 and ep["chosen_by"] == "rehearsal" and set(ep["rehearsal_device_ms_per_step_max_over_ranks"]) == {"8", "16"}
+    assert [q["rank"] for q in d["per_rank"]] == list(range(world))
+    assert d["value"] == pytest.approx(size * size * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9)
+    assert 0 < d["roofline"]["frac_wall"] and d["roofline"]["plan_key"] == "fused/fhn/f64/chunk0/map2/cols1/plain"
+
+
+def test_bench_falls_back_to_the_local_transport_and_runs_it_on_request():
+    """--transport auto: when the ring's leg fails (here: a rank count the stand-in's grid cannot be cut into -- every rank exits
+    non-zero at set-up), the LOCAL leg -- one process, all slabs, crd_group_step_rk4 -- still delivers a line, which says so; and
+    --transport local asks for that leg directly.  --gpus 1 never launches anything."""
+    common = ["--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--crd-module", "tests.standin_crd", "--preheat-ms", "0"]
+    r = _run_bench(["--gpus", "2", "--size", "64", "--transport", "local"] + common)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["n_gpus"] == 2 and d["config"]["halo"]["transport"] == "local" and "launcher" not in d["config"] and len(d["per_rank"]) == 2
+    # the ring's leg fails on every rank (exchange period out of range -> the stand-in's assertion), auto falls back
+    r = _run_bench(["--gpus", "2", "--size", "64", "--exchange-period", "2"] + common)
+    assert r.returncode != 0  # ... unless the local leg fails for the same reason: it does (same bad period), and the status says so
+    r = _run_bench(["--gpus", "2", "--size", "64"] + common, extra_env={"STANDIN_FAIL_RING": "1"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["config"]["halo"]["transport"] == "local" and d["config"]["launcher"]["transports_tried"] == ["rccl", "local"]
+    assert d["config"]["launcher"]["fallback_reasons"] and d["config"]["launcher"]["fallback_reasons"][0].startswith("rccl: rank exit codes")

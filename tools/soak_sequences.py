@@ -42,15 +42,16 @@ while time.time() - t_start < budget:
     p = crd.make_params(model, surface, nx, 80.0, 20.0, 0.12, beta, ny=ny, t_boundary=t_b, precision=precision,
                         vary_beta=int(model == "fhn" and rng.integers(2)), beta_min=0.7, beta_max=1.7)
     dt = float(rng.uniform(0.3, 0.8)) * crd.stable_dt(p)
-    os.environ["CRD_GROUP_THREADS"] = str(int(rng.integers(1, n_slabs + 1)))  # read by crd_group_step_rk4 at every call
+    threads = int(rng.integers(1, n_slabs + 1))
     cfg = crd.run_config(p, wave_length=0.1, wave_width=0.5, wave_inside=int(rng.integers(2)))
     y = crd.initial_conditions(cfg)
     single = crd.Slab(p)
     group = crd.LocalGroup(p, n_slabs)
+    group.set_threads(threads)
     ring = crd.Slab(p)
     ring.init_rccl(crd.rccl_unique_id())
-    log = ["episode %d: %s %s %dx%d %s, %d slabs, threads %s, dt %.3g, tBoundary %.3g" % (episode, model, surface, nx, ny, precision, n_slabs,
-                                                                                         os.environ["CRD_GROUP_THREADS"], dt, t_b)]
+    log = ["episode %d: %s %s %dx%d %s, %d slabs, threads %d, dt %.3g, tBoundary %.3g" % (episode, model, surface, nx, ny, precision, n_slabs,
+                                                                                         threads, dt, t_b)]
     t = 0.0
 
     def upload_all(state):

@@ -7,7 +7,10 @@ import statistics
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["CRD_TUNING"] = "1"  # the library honours the launch-time knobs only under this switch
+os.environ["CRD_TUNING"] = "1"  # honoured by a TUNING build only: `tools/build_variant.sh tuning -DCRD_TUNING_BUILD`, then CRD_LIBRARY=tools/_variants/libcrd_tuning.so
+if "CRD_LIBRARY" not in os.environ:
+    sys.exit("this tool flips launch-time knobs that only a tuning build reads: tools/build_variant.sh tuning -DCRD_TUNING_BUILD && "
+             "CRD_LIBRARY=tools/_variants/libcrd_tuning.so python3 " + sys.argv[0])
 import crdmodel_amd as crd  # noqa: E402
 
 n = int(os.environ.get("TUNE_SIZE", "8192"))
