@@ -90,7 +90,7 @@ class LaunchPlan(C.Structure):
     """crd_launch_plan"""
 
     _fields_ = [("autotune", C.c_int32), ("tuned", C.c_int32), ("one_round", C.c_int32), ("xcd_mapping", C.c_int32), ("rows", C.c_int32),
-                ("columns_per_lane", C.c_int32), ("nontemporal_stores", C.c_int32), ("reserved", C.c_int32), ("ms_default", C.c_double),
+                ("columns_per_lane", C.c_int32), ("nontemporal_stores", C.c_int32), ("steps_per_launch", C.c_int32), ("ms_default", C.c_double),
                 ("ms_chosen", C.c_double)]
 
 
@@ -166,7 +166,7 @@ _SIGNATURES = {
     "crd_trace_range_pop": (None, []),
     "crd_set_autotune": (C.c_int, [_vp, C.c_int]),
     "crd_get_launch_plan": (C.c_int, [_vp, C.POINTER(LaunchPlan)]),
-    "crd_set_launch_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "crd_set_launch_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "crd_plan_launches": (C.c_int, [_vp]),
     "crd_set_diagnostics": (C.c_int, [_vp, C.c_int]),
     "crd_set_halo_slack": (C.c_int, [_vp, C.c_int]),

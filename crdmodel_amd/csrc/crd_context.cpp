@@ -171,13 +171,15 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 		c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = std::atoi(e) <= 0 ? 0 : (std::atoi(e) >= 2 ? 2 : 1);
 	// CRD_LAUNCH_PLAN=mode,mapping,columns,nt: what crd_set_launch_plan does, for a program one cannot change (crd_run under a profiler)
 	if (const char *e = std::getenv("CRD_LAUNCH_PLAN")) {
-		int m = -1, k = -1, cols = -1, nt = 0;
-		if (std::sscanf(e, "%d,%d,%d,%d", &m, &k, &cols, &nt) >= 3 && m >= 0 && m <= 2 && k >= 0 && k <= 2 && cols >= 1 && cols <= 2 && nt >= 0 && nt <= 1) {
+		int m = -1, k = -1, cols = -1, nt = 0, st = 1;
+		if (std::sscanf(e, "%d,%d,%d,%d,%d", &m, &k, &cols, &nt, &st) >= 3 && m >= 0 && m <= 2 && k >= 0 && k <= 2 && cols >= 1 && cols <= 2 && nt >= 0 && nt <= 1 && st >= 1 &&
+		    st <= 2) {
 			c->plan.tuned = c->plan.pinned = 1;
 			c->plan.one_round = m;
 			c->plan.remap = k;
 			c->plan.cols = cols;
 			c->plan.nt = nt;
+			c->plan.steps = st;
 			c->plan.rows = (int)(c->je - c->js + 1);
 		}
 	}
@@ -677,12 +679,12 @@ int crd_set_autotune(crd_ctx *c, int on)
 	return CRD_OK;
 }
 
-int crd_set_launch_plan(crd_ctx *c, int chunk_mode, int xcd_mapping, int columns_per_lane, int nontemporal_stores)
+int crd_set_launch_plan(crd_ctx *c, int chunk_mode, int xcd_mapping, int columns_per_lane, int nontemporal_stores, int steps_per_launch)
 {
 	if (!c) return CRD_EINVAL;
 	if (chunk_mode < 0 || chunk_mode > 2 || xcd_mapping < 0 || xcd_mapping > 2 || columns_per_lane < 1 || columns_per_lane > 2 || nontemporal_stores < 0 ||
-	    nontemporal_stores > 1)
-		return fail(c, CRD_EINVAL, "crd_set_launch_plan: chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1");
+	    nontemporal_stores > 1 || steps_per_launch < 1 || steps_per_launch > 2)
+		return fail(c, CRD_EINVAL, "crd_set_launch_plan: chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1, steps per launch 1..2");
 	// (the error-controlled integrators' instantiations take the plan too; they step one column per lane whatever it says)
 	for (FusedPlan *pl : {&c->plan, &c->plan_embed, &c->plan_arkode}) {
 		pl->tuned = pl->pinned = 1;
@@ -690,6 +692,7 @@ int crd_set_launch_plan(crd_ctx *c, int chunk_mode, int xcd_mapping, int columns
 		pl->remap = xcd_mapping;
 		pl->cols = columns_per_lane;
 		pl->nt = nontemporal_stores;
+		pl->steps = pl == &c->plan ? steps_per_launch : 1;
 		pl->rows = c->nyl;  // (a pinned plan applies to launches of every height)
 		pl->ms_default = pl->ms_best = 0.f;
 	}
@@ -707,7 +710,7 @@ int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
 	// (without a plan the launches take the default of their precision: two columns per lane in fp32 on an even nx)
 	out->columns_per_lane = c->plan.tuned ? c->plan.cols : fused_default_columns(c->p.precision, c->nx);
 	out->nontemporal_stores = c->plan.nt;
-	out->reserved = 0;
+	out->steps_per_launch = (c->plan.tuned && c->plan.steps == 2 && fused_two_steps_supported(c->desc)) ? 2 : 1;
 	out->ms_default = c->plan.ms_default;
 	out->ms_chosen = c->plan.ms_best;
 	return CRD_OK;
@@ -717,7 +720,7 @@ int crd_launch_plan_candidate(int index, crd_launch_plan *out)
 {
 	if (!out) return CRD_EINVAL;
 	*out = crd_launch_plan{};
-	if (!fused_plan_candidate(index, &out->one_round, &out->xcd_mapping, &out->columns_per_lane, &out->nontemporal_stores)) return CRD_EINVAL;
+	if (!fused_plan_candidate(index, &out->one_round, &out->xcd_mapping, &out->columns_per_lane, &out->nontemporal_stores, &out->steps_per_launch)) return CRD_EINVAL;
 	return CRD_OK;
 }
 

@@ -165,7 +165,8 @@ struct crd_ctx {
 	int exchange_every = crd::kDefaultExchangeEvery;  // E: fused steps per deep-halo exchange (crd_set_exchange_period), the same on every slab of a run
 	int group_threads = 0;  // lead context of a LOCAL group: issuing threads of crd_group_step_rk4 (0 = one per device)
 	bool ghost_deferred = false;  // step 0 of the cycle has launched its owned-only rows; its ghost readers wait for step 1
-	double deferred_t = 0.0;      // that step's time
+	double deferred_t = 0.0;      // that launch's time
+	int deferred_nsub = 1;        // ... and how many steps it takes (1, or 2 under a two-steps-per-launch plan)
 	int cycle_pos = -1;
 	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
 	int cycle_start = -1;  // the decision for the call in progress, taken for ALL slabs of the run before any thread issues (run_steps)

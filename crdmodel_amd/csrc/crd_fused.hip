@@ -43,6 +43,13 @@ constexpr int kMaxWavesPerBlock = 4;  // (8 strips per workgroup never measured 
 #ifndef CRD_PREFETCH_GB
 #define CRD_PREFETCH_GB 4
 #endif
+// Rows in flight per wavefront of the two-steps-per-launch pipeline: 2 (an iteration is twice the arithmetic, so two rows cover the
+// time four cover in the one-step pipeline) -- and the 8 / 16 registers less are what takes fp32 x 2 columns and fp64 x 1 column from
+// 176 to 168 VGPRs, i.e. from two to three wavefronts per SIMD: 8192^2 fp64 0.2880 -> 0.2669 ms per step, fp32 0.1442 -> 0.1361
+// (profiles/r04/two_step_tune.txt).
+#ifndef CRD_PREFETCH_TWO
+#define CRD_PREFETCH_TWO 2
+#endif
 #ifndef CRD_EMBED_SLOTS
 #define CRD_EMBED_SLOTS 6
 #endif
@@ -160,6 +167,7 @@ struct FusedArgs {
 	Real *out_u, *out_v;      // new state, local row 0
 	Real h2, h3, h6, h1;      // dt/2, dt/3, dt/6, dt
 	int absorb[5];            // t_stage < tBoundary for the four stages (+ the embedded pair's fifth)
+	int absorb2[4];           // two steps per launch: the second step's stages
 	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
 	// Rows this launch produces: one or two ranges, cut into work items ("chunks") of `chunk` rows; chunk ids run through the
 	// ranges in order (range 1 starts at id `first2`).  One range: an ordinary sweep.  Two: the rows of a step that read ghost
@@ -449,13 +457,168 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 	}
 }
 
+// TWO classical RK4 steps of the item's rows in one pass over memory (STEPS = 2; round 4): the pipeline of fused_item twice over,
+// eight stages deep -- iteration m takes row p from memory, runs stages 1..4 of step n on rows p-1 .. p-4, hands the new row p-4
+// to a second, identical pipeline as ITS input row, which runs stages 1..4 of step n+1 on rows p-5 .. p-8 and stores row p-8.
+// The state crosses memory once per TWO steps: 8 B (fp32) / 16 B (fp64) per grid-point-step instead of 16 / 32.  What it costs:
+// the apron is 8 columns and 8 rows a side (112 valid columns of 128 with two columns per lane; 16 fill iterations per chunk,
+// hence 64-row chunks), twice the pipeline registers (two or three wavefronts per SIMD instead of four), and the first 16
+// iterations of a chunk run every stage on rows that are not all there yet -- harmless (nothing of them is stored, and the
+// arithmetic has no traps) and cheaper than sixteen specialised prologue iterations in the instruction cache.
+// Slot arithmetic: row r of either pipeline lives in slot r mod 4; the second pipeline's rows are the first one's shifted by 4,
+// i.e. the SAME slots -- the stage code is one lambda applied to two sets of arrays.  Per point the arithmetic is the sequence of
+// two single steps exactly (same fused multiply-adds, same constants), so the result is theirs bit for bit.
+template <typename Real, int MODEL, bool ABSORB, int COLS, bool NT>
+__device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk)
+{
+	using V = typename LaneValue<Real, COLS>::type;
+	constexpr int APRON = 2 * kApron;
+	static_assert(APRON % COLS == 0, "the apron is whole lanes");
+	constexpr int VALID = COLS * kLanes - 2 * APRON;
+	constexpr int M = 4;
+	constexpr int kPrefetch = CRD_PREFETCH_TWO;
+	static_assert(M % kPrefetch == 0, "prefetch slots are addressed with the unrolled iteration index");
+	const int lane = threadIdx.x & (kLanes - 1);
+	const int nx = s.nx;
+	int x = strip * VALID - APRON + COLS * lane;
+	x %= nx;
+	if (x < 0) x += nx;
+	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real), ob = (unsigned)(strip * VALID + (COLS * lane - APRON)) * (unsigned)sizeof(Real);
+	const int out_col = strip * VALID + (COLS * lane - APRON);
+	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;
+
+	const int range = chunk >= a.first2 ? 1 : 0;
+	const int range_end = a.r_end[range];
+	const int j0 = a.r_begin[range] + (chunk - (range ? a.first2 : 0)) * a.chunk;
+	const int j1 = (j0 + a.chunk < range_end) ? j0 + a.chunk : range_end;
+	const int jbase = j0 - APRON;
+	const int niter = (j1 - j0) + 2 * APRON;
+	const int jlast = j1 + APRON - 1;
+
+	const V cA = *reinterpret_cast<const V *>(s.cA + x), cP = *reinterpret_cast<const V *>(s.cP + x);
+	const Real cX = s.cX, ka4 = s.ka4;
+	const V h1 = (V)a.h1, h2 = (V)a.h2, h3 = (V)a.h3, h6 = (V)a.h6;
+	const __attribute__((address_space(4))) Real *const brow = (const __attribute__((address_space(4))) Real *)(s.brow);
+	const int wrap_nyl = s.wrap ? s.nyl : 0;
+	auto row_base = [&](int j) -> ptrdiff_t {
+		j += wrap_nyl & (j >> 31);
+		j -= (j >= s.nyl) ? wrap_nyl : 0;
+		return (ptrdiff_t)j * nx;
+	};
+	auto boundary_row = [&](int j) -> bool {
+		int gj = a.js + j;
+		if (gj < 0) gj += a.ny;
+		else if (gj >= a.ny) gj -= a.ny;
+		return gj == 0 || gj == a.ny - 1;
+	};
+
+	struct Pipe {
+		V u0[M], v0[M], U1[M], U2[M], U3[M], V1[2], V2[2], V3[2], aU[M], aV[M];
+		Real bq[M];
+	};
+	Pipe A, B;
+	const V zero_v = splat<V>(0.0);
+#pragma unroll
+	for (int k = 0; k < M; k++) {
+		A.u0[k] = A.v0[k] = A.U1[k] = A.U2[k] = A.U3[k] = A.aU[k] = A.aV[k] = zero_v;
+		B.u0[k] = B.v0[k] = B.U1[k] = B.U2[k] = B.U3[k] = B.aU[k] = B.aV[k] = zero_v;
+		A.bq[k] = B.bq[k] = (Real)0;
+	}
+	A.V1[0] = A.V1[1] = A.V2[0] = A.V2[1] = A.V3[0] = A.V3[1] = zero_v;
+	B.V1[0] = B.V1[1] = B.V2[0] = B.V2[1] = B.V3[0] = B.V3[1] = zero_v;
+
+	V pu[kPrefetch], pv[kPrefetch];
+	Real pb[kPrefetch];
+#pragma unroll
+	for (int k = 0; k < kPrefetch; k++) {
+		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
+		const ptrdiff_t rb = row_base(jr);
+		pu[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
+		pv[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
+		pb[k] = brow[jr];
+	}
+	int jn = (jbase + kPrefetch < jlast) ? jbase + kPrefetch : jlast;
+	Real *out_row_u = a.out_u + (ptrdiff_t)(jbase - 2 * kApron) * nx, *out_row_v = a.out_v + (ptrdiff_t)(jbase - 2 * kApron) * nx;
+
+	// Stages 1..4 of one step on the pipeline P whose newest row is `p` (slot S0): new state of row p - 4 in (nu, nv).
+	// absorb: the step's four stage flags; b4: b(j) of row p - 4 (read by the caller before row p took over its slot).
+	auto stages = [&](Pipe &P, const int p, auto kk, const int *absorb, const Real b4, V &nu, V &nv) {
+		constexpr int K = decltype(kk)::value;
+		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M, S5 = (K + 2 * M - 5) % M;
+		V du, dv;
+		rhs_point<V, MODEL>(P.u0[S1], from_lane_below(P.u0[S1]), from_lane_above(P.u0[S1]), P.u0[S2], P.u0[S0], P.v0[S1], cA, cX, cP, P.bq[S1], ka4,
+		                       ABSORB && absorb[0] && boundary_row(p - 1), du, dv);
+		P.U1[S1] = fmadd(h2, du, P.u0[S1]);
+		P.V1[S1 & 1] = fmadd(h2, dv, P.v0[S1]);
+		P.aU[S1] = fmadd(h6, du, P.u0[S1]);
+		P.aV[S1] = fmadd(h6, dv, P.v0[S1]);
+		rhs_point<V, MODEL>(P.U1[S2], from_lane_below(P.U1[S2]), from_lane_above(P.U1[S2]), P.U1[S3], P.U1[S1], P.V1[S2 & 1], cA, cX, cP, P.bq[S2], ka4,
+		                       ABSORB && absorb[1] && boundary_row(p - 2), du, dv);
+		P.U2[S2] = fmadd(h2, du, P.u0[S2]);
+		P.V2[S2 & 1] = fmadd(h2, dv, P.v0[S2]);
+		P.aU[S2] = fmadd(h3, du, P.aU[S2]);
+		P.aV[S2] = fmadd(h3, dv, P.aV[S2]);
+		rhs_point<V, MODEL>(P.U2[S3], from_lane_below(P.U2[S3]), from_lane_above(P.U2[S3]), P.U2[S4], P.U2[S2], P.V2[S3 & 1], cA, cX, cP, P.bq[S3], ka4,
+		                       ABSORB && absorb[2] && boundary_row(p - 3), du, dv);
+		P.U3[S3] = fmadd(h1, du, P.u0[S3]);
+		P.V3[S3 & 1] = fmadd(h1, dv, P.v0[S3]);
+		P.aU[S3] = fmadd(h3, du, P.aU[S3]);
+		P.aV[S3] = fmadd(h3, dv, P.aV[S3]);
+		rhs_point<V, MODEL>(P.U3[S4], from_lane_below(P.U3[S4]), from_lane_above(P.U3[S4]), P.U3[S5], P.U3[S3], P.V3[S4 & 1], cA, cX, cP, b4, ka4,
+		                       ABSORB && absorb[3] && boundary_row(p - 4), du, dv);
+		nu = fmadd(h6, du, P.aU[S4]);
+		nv = fmadd(h6, dv, P.aV[S4]);
+	};
+	auto iteration = [&](int m, auto kk) {
+		constexpr int K = decltype(kk)::value;
+		constexpr int S0 = K % M, S4 = (K + 2 * M - 4) % M, P0 = K % kPrefetch;
+#if !defined(CRD_NO_LOCKSTEP) && !defined(CRD_NO_LOCKSTEP_TWO)
+		__builtin_amdgcn_s_barrier();
+#endif
+		const int p = jbase + m;
+		const Real b4a = A.bq[S4], b4b = B.bq[S4];
+		A.u0[S0] = pu[P0];
+		A.v0[S0] = pv[P0];
+		A.bq[S0] = uniform(pb[P0]);
+		{
+			const ptrdiff_t rb = row_base(jn);
+			pu[P0] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
+			pv[P0] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
+			pb[P0] = brow[jn];
+			jn = (jn < jlast) ? jn + 1 : jlast;
+		}
+		V nu, nv;
+		stages(A, p, kk, a.absorb, b4a, nu, nv);  // step n: the new row p - 4 ...
+		B.u0[S0] = nu;                            // ... is the second pipeline's newest row (same slot: rows shifted by 4)
+		B.v0[S0] = nv;
+		B.bq[S0] = b4a;
+		stages(B, p - kApron, kk, a.absorb2, b4b, nu, nv);  // step n + 1: the new row p - 8
+		if (m >= 4 * kApron && lane_stores) {  // rows j0 .. j1 - 1 exactly
+			row_store<NT>(at_lane_as<V>(out_row_u, ob), nu);
+			row_store<NT>(at_lane_as<V>(out_row_v, ob), nv);
+		}
+		out_row_u += nx;
+		out_row_v += nx;
+	};
+	int m = 0;
+	for (; m + M - 1 < niter; m += M)
+		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k); }, std::make_integer_sequence<int, M>{});
+	for_sequence(
+	    [&](auto k) {
+		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k);
+	    },
+	    std::make_integer_sequence<int, M - 1>{});
+}
+
 // ABSORB = false: no stage of the step has t < tBoundary (every launch after the switch-off time, every launch of a run with
 // tBoundary = 0) -- the absorbing-row selects are compiled out.  ABSORB = true: the items that can meet a global phi boundary row
 // (src/FHNmodel_torus.cpp:643-653) run the body with the selects, all others the body without (see fused_item).
 // EMBED, COLS, NT: see FusedArgs / fused_item above.
-template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false>
+// STEPS = 2: two steps per launch (fused_item_two_steps).
+template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false, int STEPS = 1>
 __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
+	static_assert(STEPS == 1 || (STEPS == 2 && EMBED == 0), "two steps per launch: the plain step only");
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
 	// per-row table reads, the boundary-row tests) in scalar registers.
 	// Optional remap: blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of items.
@@ -487,14 +650,21 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	if constexpr (ABSORB) {
 		// Does any row this chunk's pipeline touches -- [j0 - APRON, j1 + APRON) -- map to global row 0 or ny - 1?  The two are
 		// neighbours on the periodic grid: the rows contain one of them exactly when [lo, hi + 1] contains a multiple of ny.
-		constexpr int APRON = EMBED != 0 ? kApron + 1 : kApron;
+		constexpr int APRON = STEPS * (EMBED != 0 ? kApron + 1 : kApron);
 		const int range = chunk >= a.first2 ? 1 : 0;
 		const int j0 = a.r_begin[range] + (chunk - (range ? a.first2 : 0)) * a.chunk;
 		const int j1 = (j0 + a.chunk < a.r_end[range]) ? j0 + a.chunk : a.r_end[range];
 		const int lo = a.js + j0 - APRON, hi1 = a.js + j1 + APRON;  // (lo > -ny and hi1 < 3 ny: a slab is at most the grid, ghost rows at most a slab)
 		const bool touches = (lo <= 0 && 0 <= hi1) || (lo <= a.ny && a.ny <= hi1) || (lo <= 2 * a.ny && 2 * a.ny <= hi1);
-		if (touches) fused_item<Real, MODEL, true, EMBED, COLS, NT>(s, a, strip, chunk);
-		else fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
+		if constexpr (STEPS == 2) {
+			if (touches) fused_item_two_steps<Real, MODEL, true, COLS, NT>(s, a, strip, chunk);
+			else fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk);
+		} else {
+			if (touches) fused_item<Real, MODEL, true, EMBED, COLS, NT>(s, a, strip, chunk);
+			else fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
+		}
+	} else if constexpr (STEPS == 2) {
+		fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk);
 	} else {
 		fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
 	}
@@ -539,14 +709,14 @@ int device_cus()
 	return cus;
 }
 
-template <typename Real, int MODEL, int COLS>
+template <typename Real, int MODEL, int COLS, int STEPS>
 int resident_wavefronts()
 {
 	// resident wavefronts of this kernel on a device of this node (initialised once, thread-safely: the issuing threads of a LOCAL group
 	// may arrive together)
 	static const int slots = [] {
 		int blocks_per_cu = 4;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0, COLS, false>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0, COLS, false, STEPS>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
 		    blocks_per_cu < 1)
 			blocks_per_cu = 4;
 		(void)hipGetLastError();
@@ -556,28 +726,33 @@ int resident_wavefronts()
 }
 
 template <typename Real, int MODEL>
-int resident_wavefronts(int cols)
+int resident_wavefronts(int cols, int steps = 1)
 {
-	return cols == 2 ? resident_wavefronts<Real, MODEL, 2>() : resident_wavefronts<Real, MODEL, 1>();
+	if constexpr (MODEL != kModelDiffusionOnly)  // (the diffusion-only variant has no two-step instantiation)
+		if (steps == 2) return cols == 2 ? resident_wavefronts<Real, MODEL, 2, 2>() : resident_wavefronts<Real, MODEL, 1, 2>();
+	return cols == 2 ? resident_wavefronts<Real, MODEL, 2, 1>() : resident_wavefronts<Real, MODEL, 1, 1>();
 }
 
 template <typename Real, int MODEL>
-int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols)  // 0: 32 rows, 1: one round, 2: 64 rows
+int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols, int steps = 1)  // 0: 32 rows, 1: one round, 2: 64 rows (two steps per launch: twice that)
 {
 	bool one_round = chunk_mode == 1;
-	const int slots = resident_wavefronts<Real, MODEL>(cols);
-	int chunk = 32;
+	const int slots = resident_wavefronts<Real, MODEL>(cols, steps);
+	// Two steps per launch: 16 fill rows per chunk instead of 8, and a pipeline bound by issue, not by the memory system: 128-row
+	// chunks (8192^2 fp64: 48 rows 0.301 ms per step, 64 0.289, 96 0.278, 128 0.267, 192 0.276, 256 0.276; fp32 alike,
+	// profiles/r04/two_step_tune.txt); chunk mode 2 is the 64-row alternative there.
+	int chunk = steps == 2 ? (chunk_mode == 2 ? 64 : 128) : 32;
 	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
 	// Tiny launches: where even 8-row chunks make fewer blocks than half the CUs, 4-row chunks put twice as many CUs to work (256^2:
 	// 7.3 -> 6.4 us per step; the reference's 100 x 400 Goldbeter grid: 8.2 -> 6.5).  With more blocks than that the extra apron rows
 	// cost more than they bring (512^2: 8.9 -> 9.8 us, 400 x 1600: 11.1 -> 12.9; the edge bands of a ring share: no change).
 	if (chunk == 8 && (long)((nstrips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + 7) / 8) < device_cus() / 2) chunk = 4;
 	if (const char *e = tuning::knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
-	if (chunk_mode == 2 && chunk == 32 && (long)nstrips * ((rows + 63) / 64) >= 2L * slots) chunk = 64;  // fewer apron rows recomputed: pays where fp64 issue binds (Goldbeter)
+	if (steps == 1 && chunk_mode == 2 && chunk == 32 && (long)nstrips * ((rows + 63) / 64) >= 2L * slots) chunk = 64;  // fewer apron rows recomputed: pays where fp64 issue binds (Goldbeter)
 	if (one_round) {
 		const long strip_blocks = (nstrips + kWavesPerBlock - 1) / kWavesPerBlock, fit = (slots / kWavesPerBlock) / strip_blocks;
 		const long need = fit >= 1 ? (rows + fit - 1) / fit : 0;
-		if (need > chunk && need <= 96) chunk = (int)need;
+		if (need > chunk && need <= 96 * steps) chunk = (int)need;  // (two steps per launch: up to 192 rows)
 	}
 	if (const char *e = tuning::knob("CRD_FUSED_CHUNK")) {  // tuning knob
 		const int v = std::atoi(e);
@@ -603,6 +778,7 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols)  // 0: 32 
 // mapping is fastest changes with them (the plain mapping gains most), so they are timed in combination.
 struct PlanCandidate {
 	int one_round, remap, cols, nt;  // one_round: the chunk mode -- 0 = 32 rows, 1 = stretched to one round, 2 = 64 rows
+	int steps = 1;                   // RK4 steps per launch (2: fused_item_two_steps)
 };
 // (round 4: 64-row chunks also under mappings 1 / 2 and with two columns per lane -- where fp64 issue binds, Goldbeter, the recompute
 // factor of the apron rows is what is left to cut: (64 + 8) / 64 x 128 / 120 = 1.20 against (32 + 8) / 32 x 64 / 56 = 1.43)
@@ -610,7 +786,9 @@ constexpr PlanCandidate kPlanCandidates[] = {
     {0, 0, 1, 0}, {0, 1, 1, 0}, {0, 2, 1, 0}, {1, 0, 1, 0}, {1, 1, 1, 0}, {2, 0, 1, 0}, {2, 1, 1, 0}, {2, 2, 1, 0},
     {0, 0, 2, 0}, {0, 1, 2, 0}, {0, 2, 2, 0}, {1, 0, 2, 0}, {1, 1, 2, 0}, {2, 0, 2, 0}, {2, 1, 2, 0}, {2, 2, 2, 0},
     {0, 0, 1, 1}, {0, 1, 1, 1}, {0, 2, 1, 1}, {1, 0, 1, 1}, {1, 1, 1, 1}, {2, 0, 1, 1}, {2, 1, 1, 1}, {2, 2, 1, 1},
-    {0, 0, 2, 1}, {0, 1, 2, 1}, {0, 2, 2, 1}, {1, 0, 2, 1}, {1, 1, 2, 1}, {2, 0, 2, 1}, {2, 1, 2, 1}, {2, 2, 2, 1}};
+    {0, 0, 2, 1}, {0, 1, 2, 1}, {0, 2, 2, 1}, {1, 0, 2, 1}, {1, 1, 2, 1}, {2, 0, 2, 1}, {2, 1, 2, 1}, {2, 2, 2, 1},
+    // fifth dimension (round 4): two steps per launch (128-row chunks, or 64), non-temporal stores
+    {0, 0, 1, 1, 2}, {0, 1, 1, 1, 2}, {0, 2, 1, 1, 2}, {2, 1, 1, 1, 2}, {0, 0, 2, 1, 2}, {0, 1, 2, 1, 2}, {0, 2, 2, 1, 2}, {2, 1, 2, 1, 2}};
 constexpr int kNumPlanCandidates = (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]);
 
 template <typename Real, int MODEL>
@@ -620,8 +798,11 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	clear_launch_status();
 	if (row_end <= row_begin) return hipSuccess;
 	if (row_end2 < row_begin2) row_end2 = row_begin2;
-	// rows may extend into the ghost region (deep-halo steps), but the pipeline reads kStepHalo rows beyond them
-	if (!d.wrap && (row_begin < -(kGhost - kStepHalo) || row_end > d.nyl + (kGhost - kStepHalo))) return hipErrorInvalidValue;
+	// Two steps per launch: plain steps only, and not the diffusion-only variant (no instantiation: that model is a plumbing case).
+	constexpr bool kCanTwoSteps = MODEL != kModelDiffusionOnly;
+	if (c.steps != 1 && (c.steps != 2 || c.embed || !kCanTwoSteps)) return hipErrorInvalidValue;
+	// rows may extend into the ghost region (deep-halo steps), but the pipeline reads kStepHalo rows per step beyond them
+	if (!d.wrap && (row_begin < -(kGhost - c.steps * kStepHalo) || row_end > d.nyl + (kGhost - c.steps * kStepHalo))) return hipErrorInvalidValue;
 	const Slab<Real> s = typed<Real>(d);
 	FusedArgs<Real> a;
 	a.in_u = row0<Real>(c.y0.u, d.nx);
@@ -633,6 +814,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.h6 = (Real)(c.dt / 6.0);
 	a.h1 = (Real)c.dt;
 	for (int k = 0; k < 5; k++) a.absorb[k] = c.absorb[k];
+	for (int k = 0; k < 4; k++) a.absorb2[k] = c.absorb2[k];
 	a.js = js;
 	a.ny = ny;
 	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
@@ -655,20 +837,22 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.atol = (Real)c.atol;
 	// the reaction block of a diffusion-only run is skipped, absorbing rows included (src/GoldbeterModel_torus.cpp:668)
 	constexpr bool kCanAbsorb = MODEL != kModelDiffusionOnly;
-	const bool absorb = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3] || (c.embed && c.absorb[4]));
+	const bool absorb1 = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3] || (c.embed && c.absorb[4]));
+	const bool absorb12 = absorb1 || (kCanAbsorb && (c.absorb2[0] || c.absorb2[1] || c.absorb2[2] || c.absorb2[3]));
 	const dim3 block(kLanes * sw);
 
-	int cols = cols_default;
+	int cols = cols_default, steps = 1;
 	bool nt = false;
-	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0) {
+	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0, int want_steps = 1) {
+		steps = (want_steps == 2 && kCanTwoSteps) ? 2 : 1;
 		nt = want_nt != 0;
 		if (const char *e = tuning::knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0;
 		cols = (want_cols == 2 && cols2_ok) ? 2 : 1;
 		if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
-		const int valid = cols * kLanes - 2 * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
+		const int valid = cols * kLanes - 2 * steps * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
 		a.nstrips = (d.nx + valid - 1) / valid;
 		const int nsb = (a.nstrips + sw - 1) / sw;
-		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round, cols);
+		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round, cols, steps);
 		const int n1 = (rows + a.chunk - 1) / a.chunk, n2 = (rows2 + a.chunk - 1) / a.chunk;
 		a.nchunks = n1 + n2;
 		a.first2 = n2 > 0 ? n1 : a.nchunks;
@@ -682,7 +866,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		if (const char *e = tuning::knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);
 		a.xs_lanes = 1;
 		if (a.remap == 2) {
-			const int per_xcd = resident_wavefronts<Real, MODEL>(cols) / sw / kNumXcd;
+			const int per_xcd = resident_wavefronts<Real, MODEL>(cols, steps) / sw / kNumXcd;
 			if (rows2 > 0 || a.nchunks < 2 * kNumXcd || per_xcd < nsb) {
 				a.remap = 0;  // two row ranges, or too few chunks / slots for lanes: plain order
 			} else {
@@ -707,24 +891,28 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (nt) with_embed(absorb_c, std::true_type{});
 				else with_embed(absorb_c, std::false_type{});
 			};
-			if (absorb) with_nt(std::true_type{});
+			if (absorb1) with_nt(std::true_type{});
 			else with_nt(std::false_type{});
 			crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
 		} else {
-			// plain step: absorbing rows x columns per lane x store hint, all compile-time
-			auto with = [&](auto absorb_c, auto cols_c, auto nt_c) {
-				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value>
-				    <<<a.nblocks, block, 0, st>>>(s, a);
+			// plain step: absorbing rows x columns per lane x store hint x steps per launch, all compile-time
+			auto with = [&](auto absorb_c, auto cols_c, auto nt_c, auto steps_c) {
+				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value,
+				                          kCanTwoSteps ? decltype(steps_c)::value : 1><<<a.nblocks, block, 0, st>>>(s, a);
+			};
+			auto with_steps = [&](auto absorb_c, auto cols_c, auto nt_c) {
+				if (steps == 2) with(absorb_c, cols_c, nt_c, std::integral_constant<int, 2>{});
+				else with(absorb_c, cols_c, nt_c, std::integral_constant<int, 1>{});
 			};
 			auto with_cols = [&](auto absorb_c, auto nt_c) {
-				if (cols == 2) with(absorb_c, std::integral_constant<int, 2>{}, nt_c);
-				else with(absorb_c, std::integral_constant<int, 1>{}, nt_c);
+				if (cols == 2) with_steps(absorb_c, std::integral_constant<int, 2>{}, nt_c);
+				else with_steps(absorb_c, std::integral_constant<int, 1>{}, nt_c);
 			};
 			auto with_nt = [&](auto absorb_c) {
 				if (nt) with_cols(absorb_c, std::true_type{});
 				else with_cols(absorb_c, std::false_type{});
 			};
-			if (absorb) with_nt(std::true_type{});
+			if (steps == 2 ? absorb12 : absorb1) with_nt(std::true_type{});
 			else with_nt(std::false_type{});
 		}
 		return launch_status();
@@ -769,13 +957,16 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		// measurement runs (a Goldbeter launch sequence lost 15 % over five candidates timed one after the other), and a
 		// candidate must not win or lose by its place in the queue.
 		constexpr int kCandidates = kNumPlanCandidates, kRounds = 3;
+		const bool two_steps_ok = kCanTwoSteps && !c.embed && c.steps == 1 && d.nyl >= 4 * kStepHalo;  // (the caller steps pairs once the plan says so)
 		float t_best[kCandidates];
 		bool live[kCandidates];
 		int reps = 3;
 		for (int k = 0; k < kCandidates; k++) {
 			t_best[k] = 0.f;
-			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt);
-			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols));  // (same as a 32-row plan)
+			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt, kPlanCandidates[k].steps);
+			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols, steps));  // (same as a 32-row plan)
+			if (live[k] && kPlanCandidates[k].steps != (two_steps_ok ? steps : 1)) live[k] = false;  // (two steps per launch: plain steps)
+			if (live[k] && steps == 2 && cols == 2 && sizeof(Real) == 8) live[k] = false;  // (256 VGPRs, one wavefront per SIMD: measured 0.347 against 0.312 ms)
 			if (live[k] && kPlanCandidates[k].remap != a.remap) live[k] = false;  // (the mapping fell back to dispatch order)
 			if (live[k] && kPlanCandidates[k].cols != cols) live[k] = false;      // (two columns per lane not possible here, or pinned by a knob)
 			if (live[k] && (kPlanCandidates[k].nt != 0) != nt) live[k] = false;   // (pinned by a knob)
@@ -783,7 +974,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		for (int round = 0; round < kRounds && err == hipSuccess; round++)
 			for (int k = 0; err == hipSuccess && k < kCandidates; k++) {
 				if (!live[k]) continue;
-				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt);
+				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt, kPlanCandidates[k].steps);
 				float ms = 0.f;
 				for (int pass = 0; pass < 2 && err == hipSuccess; pass++) {
 					err = fire_timed();  // warm-up of this variant
@@ -796,10 +987,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 					reps = (int)(12.0f / ms) + 1 < 40 ? (int)(12.0f / ms) + 1 : 40;  // time about four milliseconds' worth per candidate and round, then again
 				}
 				if (err != hipSuccess) break;
-				ms /= (float)reps;
+				ms /= (float)(reps * steps);  // per STEP: a two-step launch does twice the work
 				if ((plan->autotune >= 2 || tuning::verbose()))
-					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores: %.4f ms per launch (%d launches timed)\n",
-					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, nt ? "non-temporal" : "plain", ms, reps);
+					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores, %d step(s) per launch: %.4f ms per step (%d launches timed)\n",
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, nt ? "non-temporal" : "plain", steps, ms, reps);
 				if (t_best[k] == 0.f || ms < t_best[k]) t_best[k] = ms;
 			}
 		// Final: with two dozen candidates a few per cent apart, the fastest of the short bursts above is as often the luckiest as
@@ -817,7 +1008,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 			for (int f = 0; err == hipSuccess && f < kFinalists; f++) {
 				const int k = finalist[f];
 				if (k < 0 || t_best[k] <= 0.f) continue;
-				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt);
+				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt, kPlanCandidates[k].steps);
 				const int reps2 = (int)(16.0f / t_best[k]) + 1 < 400 ? (int)(16.0f / t_best[k]) + 1 : 400;
 				float ms = 0.f;
 				err = fire_timed();
@@ -827,10 +1018,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (err == hipSuccess) err = hipEventSynchronize(e1);
 				if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
 				if (err != hipSuccess) break;
-				ms /= (float)reps2;
+				ms /= (float)(reps2 * steps);
 				if ((plan->autotune >= 2 || tuning::verbose()))
-					std::fprintf(stderr, "libcrd autotune: %d x %d rows, final %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores: %.4f ms per launch (%d launches timed)\n",
-					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, nt ? "non-temporal" : "plain", ms, reps2);
+					std::fprintf(stderr, "libcrd autotune: %d x %d rows, final %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores, %d step(s) per launch: %.4f ms per step (%d launches timed)\n",
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, nt ? "non-temporal" : "plain", steps, ms, reps2);
 				if (t_final[f] == 0.f || ms < t_final[f]) t_final[f] = ms;
 			}
 		int best_k = 0;
@@ -853,6 +1044,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		plan->remap = kPlanCandidates[best_k].remap;
 		plan->cols = kPlanCandidates[best_k].cols;
 		plan->nt = kPlanCandidates[best_k].nt;
+		plan->steps = kPlanCandidates[best_k].steps;
 		plan->rows = rows;
 		plan->ms_default = base;
 		plan->ms_best = best_k ? best : base;
@@ -864,13 +1056,15 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	// where the launch is too small for them), two-range launches its columns per lane and store hint.
 	const bool pinned = plan && plan->tuned && plan->pinned && !tuning::enabled();
 	const bool use_plan = (plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows) || (pinned && rows2 == 0);
-	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default, (use_plan || pinned) ? plan->nt : 0);
+	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default, (use_plan || pinned) ? plan->nt : 0, c.steps);
 	return fire();
 }
 
 }  // namespace
 
 bool fused_step_supported(int, const SlabDesc &d) { return d.nyl >= 2 * kStepHalo; }
+
+bool fused_two_steps_supported(const SlabDesc &d) { return d.nyl >= 4 * kStepHalo && kernel_model(d) != kModelDiffusionOnly; }
 
 int fused_max_items(const SlabDesc &d)
 {
@@ -886,9 +1080,10 @@ int fused_default_columns(int precision, int nx) { return (precision == CRD_PREC
 
 int fused_plan_candidates() { return kNumPlanCandidates; }
 
-bool fused_plan_candidate(int index, int *chunk_mode, int *mapping, int *cols, int *nt)
+bool fused_plan_candidate(int index, int *chunk_mode, int *mapping, int *cols, int *nt, int *steps)
 {
 	if (index < 0 || index >= kNumPlanCandidates) return false;
+	*steps = kPlanCandidates[index].steps;
 	*chunk_mode = kPlanCandidates[index].one_round;
 	*mapping = kPlanCandidates[index].remap;
 	*cols = kPlanCandidates[index].cols;

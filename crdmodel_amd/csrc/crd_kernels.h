@@ -68,6 +68,7 @@ struct FusedPlan {
 	int one_round = 0, remap = 0;
 	int cols = 1;                          // grid columns per lane (1 or 2)
 	int nt = 0;                            // the new state stored with the non-temporal hint
+	int steps = 1;                         // RK4 steps per launch (2: single slabs only; the stepping loop then issues pairs)
 	int rows = 0;                          // height of the launch the plan was measured on
 	float ms_default = 0.f, ms_best = 0.f;  // measured launch times of the plain plan and of the chosen one
 };
@@ -75,6 +76,8 @@ struct FusedPlan {
 struct FusedCall {
 	double dt;
 	int absorb[5];  // four stages + the embedded pair's fifth (embed = 1: t + dt; embed = 2: t + 3/4 dt)
+	int absorb2[4] = {0, 0, 0, 0};  // the stages of the step after this one (t + dt + c_k dt): read by a two-step launch
+	int steps = 1;  // 2: this launch advances the rows by TWO steps (single slab, no second row range, no error estimate)
 	Planes y0;
 	Planes yout;
 	// embedded error estimate (adaptive stepping): weighted square sum of the local error over the launch's rows
@@ -95,7 +98,8 @@ const char *fused_kernel_name(int precision, int model);
 bool fused_step_supported(int precision, const SlabDesc &d);
 int fused_default_columns(int precision, int nx);  // columns per lane of launches without a measured plan
 int fused_plan_candidates();                       // the plans the tuner times (crd_launch_plan_candidate)
-bool fused_plan_candidate(int index, int *chunk_mode, int *mapping, int *cols, int *nt);
+bool fused_plan_candidate(int index, int *chunk_mode, int *mapping, int *cols, int *nt, int *steps);
+bool fused_two_steps_supported(const SlabDesc &d);
 int fused_max_items(const SlabDesc &d);
 
 // Layout adaptors between the AoS boundary layout (host precision: f64 or device precision) and SoA planes.

@@ -43,9 +43,10 @@ int staged_step_self(crd_ctx *c, double t, double dt, hipEvent_t *k_begin, hipEv
 	return CRD_OK;
 }
 
-int fused_step_self(crd_ctx *c, double t, double dt, int src, int dst, hipEvent_t *k_begin, hipEvent_t *k_end)
+int fused_step_self(crd_ctx *c, double t, double dt, int src, int dst, hipEvent_t *k_begin, hipEvent_t *k_end, int steps = 1)
 {
-	const FusedCall call = make_fused_call(c, t, dt, src, dst);
+	FusedCall call = make_fused_call(c, t, dt, src, dst);
+	call.steps = steps;  // 2: this one launch takes the state from t to t + 2 dt
 	if (k_begin) HIP_TRY(c, hipEventRecord(*k_begin, c->compute));
 	HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
 	if (k_end) HIP_TRY(c, hipEventRecord(*k_end, c->compute));
@@ -144,59 +145,68 @@ int wait_for_halo(crd_ctx *c)
 	return CRD_OK;
 }
 
-int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, bool timed_step, bool last_step_of_call)
+// One launch of the cycle on every context of the call: `nsub` steps (1, or 2 with a two-steps-per-launch plan: the pair must not
+// straddle an exchange, q + nsub <= E) from cycle position q.  H = 4 nsub rows are consumed beyond the rows produced.
+int fused_launch_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, int nsub, bool timed_step, bool last_launch_of_call)
 {
 	const int E = cycle_steps(cs[0]), G = cycle_ghost(cs[0]), B = cycle_band(cs[0]);
-	const int ext = kStepHalo * (E - 1 - q);
-	if (q < E - 1) {
+	const int H = kStepHalo * nsub;
+	const int ext = kStepHalo * (E - q - nsub);  // ghost rows still valid once this launch has run
+	auto call_of = [&](crd_ctx *c, double tt, int from, int to, int steps) {
+		FusedCall call = make_fused_call(c, tt, dt, from, to);
+		call.steps = steps;
+		return call;
+	};
+	if (q + nsub < E) {
 		for (int k = 0; k < n; k++) {
 			crd_ctx *c = cs[k];
 			if (int rc = set_device(c)) return rc;
-			const FusedCall call = make_fused_call(c, t, dt, src, dst);
+			const FusedCall call = call_of(c, t, src, dst, nsub);
 			const bool timed = timed_step && !c->ev_k.empty();
-			if (q == 1 && c->ghost_deferred) {
-				// Halo slack 2 (crd_set_halo_slack): the exchange gets a THIRD sweep to land under.  The cycle's first step has only
-				// launched its rows that read owned rows; this step does the same -- rows [B, nyl - B) only, B = the band the
+			if (c->ghost_deferred) {
+				// Halo slack 2 (crd_set_halo_slack): the exchange gets a THIRD sweep to land under.  The cycle's first launch has only
+				// produced its rows that read owned rows; this one does the same -- rows [B, nyl - B) only, B = the band the
 				// exchange sends from / the neighbours pull from, which nobody may overwrite before the exchange is through -- and
-				// only then the compute stream waits, finishes step 0 (the rows that read ghost rows) and step 1 (its edges).
-				const FusedCall call0 = make_fused_call(c, c->deferred_t, dt, dst, src);  // step 0 read this step's output plane and wrote its input plane
-				const int ext0 = kStepHalo * (E - 1);
+				// only then the compute stream waits, finishes the first launch (the rows that read ghost rows) and this one (its edges).
+				const int n0 = c->deferred_nsub, H0 = kStepHalo * n0, ext0 = kStepHalo * (E - n0);
+				const FusedCall call0 = call_of(c, c->deferred_t, dst, src, n0);  // the first launch read this launch's output plane and wrote its input plane
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, B, c->nyl - B, 0, 0, c->compute));
 				if (int rc = wait_for_halo(c)) return rc;
-				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call0, -ext0, kStepHalo, c->nyl - kStepHalo, c->nyl + ext0, c->compute));
+				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call0, -ext0, H0, c->nyl - H0, c->nyl + ext0, c->compute));
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, B, c->nyl - B, c->nyl + ext, c->compute));
 				c->ghost_deferred = false;
 				continue;
 			}
 			if (q > 0) {
-				// (nothing to record: the next step runs on the same stream)
+				// (nothing to record: the next launch runs on the same stream)
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
 				if (timed) c->timed_rows = c->nyl + 2 * ext;  // what crd_dominant_kernel_rows reports for this launch
 				continue;
 			}
-			// First step after an exchange.  Output rows [kStepHalo, nyl - kStepHalo) read owned rows only, so they are launched
-			// straight behind the interior sweep of the previous step: the exchange gets this sweep as extra time to land.
+			// First launch after an exchange.  Output rows [H, nyl - H) read owned rows only, so they are launched straight behind
+			// the interior sweep of the previous launch: the exchange gets this sweep as extra time to land.
 			const bool split = c->nyl >= 4 * B;
-			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, kStepHalo, c->nyl - kStepHalo, 0, 0, c->compute));
-			if (split && c->halo_slack >= 2 && !last_step_of_call && E > 3) {
-				c->ghost_deferred = true;  // the wait and the rows that read ghost rows follow behind the NEXT step's owned-only rows
+			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, H, c->nyl - H, 0, 0, c->compute));
+			if (split && c->halo_slack >= 2 && !last_launch_of_call && q + nsub + 2 < E) {  // (whatever the next launch takes, one or two steps, it is not the cycle's last)
+				c->ghost_deferred = true;  // the wait and the rows that read ghost rows follow behind the NEXT launch's owned-only rows
 				c->deferred_t = t;
+				c->deferred_nsub = nsub;
 				continue;
 			}
 			if (int rc = wait_for_halo(c)) return rc;
-			// the rows that read ghost rows: [-ext, kStepHalo) and [nyl - kStepHalo, nyl + ext) in one launch
-			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, kStepHalo, c->nyl - kStepHalo, c->nyl + ext, c->compute));
+			// the rows that read ghost rows: [-ext, H) and [nyl - H, nyl + ext) in one launch
+			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, H, c->nyl - H, c->nyl + ext, c->compute));
 			else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
 		}
 		return CRD_OK;
 	}
-	// last step of the cycle: edge bands, exchange released behind them, interior under the exchange
+	// last launch of the cycle: edge bands, exchange released behind them, interior under the exchange
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
-		const FusedCall call = make_fused_call(c, t, dt, src, dst);
+		const FusedCall call = call_of(c, t, src, dst, nsub);
 		if (c->nyl >= 4 * B) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, B, c->nyl - B, c->nyl, c->compute));
 		else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
 		HIP_TRY(c, hipEventRecord(c->ev_edges, c->compute));
@@ -206,11 +216,23 @@ int fused_step_multi(crd_ctx *const *cs, int n, double t, double dt, int src, in
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
 		if (c->nyl >= 4 * B) {
-			const FusedCall call = make_fused_call(c, t, dt, src, dst);
+			const FusedCall call = call_of(c, t, src, dst, nsub);
 			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, B, c->nyl - B, 0, 0, c->compute));
 		}
 	}
 	return CRD_OK;
+}
+
+// May steps s and s + 1 of a call go out as ONE two-step launch?  The kernel takes the second step's absorbing-row flags from
+// t + dt (make_fused_call); the stepping loops form that step's time as t0 + (s + 1) dt, which may differ by a rounding -- which
+// matters only where a stage time lands within an ulp of tBoundary.  Such a pair is stepped singly, so that paired and unpaired
+// stepping take the same decisions.
+bool pair_is_exact(const crd_ctx *c, double t0, int64_t s, double dt)
+{
+	const double t = t0 + (double)s * dt, t2 = t0 + (double)(s + 1) * dt, cs4[4] = {0.0, 0.5, 0.5, 1.0};
+	for (int k = 0; k < 4; k++)
+		if (absorbing(c, t2 + cs4[k] * dt) != absorbing(c, (t + dt) + cs4[k] * dt)) return false;
+	return true;
 }
 
 // RCCL runs: one decision for the whole ring on where in the exchange cycle the call starts (see crd_ctx::agree_dev).  begin_
@@ -268,6 +290,7 @@ FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int ds
 	call.dt = dt;
 	const double cs[4] = {0.0, 0.5, 0.5, 1.0};
 	for (int k = 0; k < 4; k++) call.absorb[k] = absorbing(c, t + cs[k] * dt) ? 1 : 0;
+	for (int k = 0; k < 4; k++) call.absorb2[k] = absorbing(c, (t + dt) + cs[k] * dt) ? 1 : 0;  // the step after this one, as the stepping loop forms its time
 	call.absorb[4] = call.absorb[3];  // (the embedded pairs' fifth stage: set by the adaptive integrator)
 	call.y0 = c->planes(src);
 	call.yout = c->planes(dst);
@@ -310,25 +333,30 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		crd_ctx *c = lead;
 		if (int rc = set_device(c)) return rc;
 		int cur = crd_ctx::Y;
-		for (int64_t s = 0; s < nsteps; s++) {
+		for (int64_t s = 0; s < nsteps;) {
 			const double t = t0 + (double)s * dt;
 			hipEvent_t *kb = nullptr, *ke = nullptr;
 			// every fourth step at most: an event pair around EVERY launch of a short run would sit inside the region being timed
 			const int64_t want = std::min<int64_t>(kMaxTimedLaunches, std::max<int64_t>(1, nsteps / 4));
-			if (timed_launches && timed < want && (s * want / std::max<int64_t>(nsteps, 1)) >= timed && (s % 4 == 1 || nsteps < 4)) {
+			if (timed_launches && timed < want && (s * want / std::max<int64_t>(nsteps, 1)) >= timed && ((s % 4) >= 1 || nsteps < 4)) {
 				kb = &c->ev_k[(size_t)(2 * timed)];
 				ke = &c->ev_k[(size_t)(2 * timed + 1)];
 				timed++;
 			}
-			int rc;
+			int rc, took = 1;
 			if (stepper == CRD_STEPPER_STAGED) {
 				rc = staged_step_self(c, t, dt, kb, ke);
 			} else {
+				// The plan may say "two steps per launch" (measured, or pinned): pairs while two steps are left, a single-step launch
+				// for an odd last one (pair_is_exact: see there).
+				const bool pair = c->plan.tuned && c->plan.steps == 2 && s + 2 <= nsteps && fused_two_steps_supported(c->desc);
+				took = (pair && pair_is_exact(c, t0, s, dt)) ? 2 : 1;
 				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
-				rc = fused_step_self(c, t, dt, cur, dst, kb, ke);
+				rc = fused_step_self(c, t, dt, cur, dst, kb, ke, took);
 				cur = dst;
 			}
 			if (rc) return rc;
+			s += took;
 		}
 		if (cur != crd_ctx::Y) {  // odd number of fused steps: the result sits in SA; swap the plane pointers
 			std::swap(c->plane[crd_ctx::Y][0], c->plane[crd_ctx::SA][0]);
@@ -357,7 +385,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			if (ring) {
 				if (int rc = begin_cycle_agreement(lead, q0)) return rc;
 				agreement_pending = true;
-				if (q0 < 0 || q0 == E - 1) {  // nothing to issue ahead of the answer
+				if (q0 < 0 || q0 >= E - 2) {  // nothing to issue ahead of the answer (the call's first launch may be the cycle's last, a pair included)
 					if (int rc = finish_cycle_agreement(lead, &q0)) return rc;
 					agreement_pending = false;
 				}
@@ -369,35 +397,42 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			}
 		}
 		int cur = crd_ctx::Y;
-		for (int64_t s = 0; s < nsteps; s++) {
+		// Two steps per launch where the lead context's plan says so (measured, or pinned): pairs that do not straddle an exchange.
+		// Where the exchanges fall in the step sequence does not depend on the pairing, so the ranks of a ring / the threads of a group
+		// may pair differently (each by its own plan) and still meet at the same collectives.
+		bool pairs = fused && lead->plan.tuned && lead->plan.steps == 2;
+		for (int k = 0; k < n; k++) pairs = pairs && fused_two_steps_supported(cs[k]->desc);
+		for (int64_t s = 0; s < nsteps;) {
 			const int q = (int)((s + q0) % E);
-			// time one launch of the dominant kernel mid-run (fused: the first one-launch step of a cycle)
-			// (fused: a step of the cycle that is one full-height launch, i.e. neither the split first nor the split last one)
-			const bool timed_step = timed_launches && !timed &&
-			                        (fused ? (q >= (lead->halo_slack >= 2 ? 2 : 1) && q <= E - 2 && (s >= nsteps / 2 || s + E >= nsteps)) : s >= nsteps / 2);
+			const int nsub = (pairs && s + 2 <= nsteps && q + 2 <= E && pair_is_exact(lead, t0, s, dt)) ? 2 : 1;
+			// time one launch of the dominant kernel mid-run (fused: a launch of the cycle that is one full-height sweep, i.e. neither
+			// the split first nor the split last one, nor the one that finishes a deferred first)
+			const bool middle = q >= (lead->halo_slack >= 2 ? 2 * nsub : 1) && q + nsub < E;
+			const bool timed_step = timed_launches && !timed && (fused ? (middle && (s >= nsteps / 2 || s + E >= nsteps)) : s >= nsteps / 2);
 			const double t = t0 + (double)s * dt;
 			if (fused) {
 				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
-				if (int rc = fused_step_multi(cs, n, t, dt, cur, dst, q, timed_step, s + 1 == nsteps)) return rc;
+				if (int rc = fused_launch_multi(cs, n, t, dt, cur, dst, q, nsub, timed_step, s + nsub == nsteps)) return rc;
 				cur = dst;
 			} else if (int rc = staged_step_multi(cs, n, t, dt, timed_step)) {
 				return rc;
 			}
 			if (timed_step) timed = 1;
-			if (agreement_pending) {  // the first step is on its way: now hear what the ring says
+			s += nsub;
+			if (agreement_pending) {  // the first launch is on its way: now hear what the ring says
 				int agreed = -1;
 				if (int rc = finish_cycle_agreement(lead, &agreed)) return rc;
 				agreement_pending = false;
 				if (agreed != q0) {
-					// Some rank holds a new state: every rank starts afresh.  The step just issued wrote the scratch planes only (plane Y
+					// Some rank holds a new state: every rank starts afresh.  The launch just issued wrote the scratch planes only (plane Y
 					// is untouched) and is overwritten by the one issued again below, in stream order.
 					lead->agreement_restarts++;
-					for (int k = 0; k < n; k++) cs[k]->ghost_deferred = false;  // (the step issued ahead of the answer is void, and so is what it deferred)
+					for (int k = 0; k < n; k++) cs[k]->ghost_deferred = false;  // (the launch issued ahead of the answer is void, and so is what it deferred)
 					if (int rc = prime_halo(cs, n, crd_ctx::Y, cycle_ghost(lead), true)) return rc;
 					q0 = 0;
 					cur = crd_ctx::Y;
 					timed = 0;
-					s = -1;
+					s = 0;
 				}
 			}
 		}

@@ -318,9 +318,9 @@ class Slab:
         """0 / False: never measure a launch plan; 1 / True: measure on the first full-size launch; 2: ... and print the timings."""
         self._check(lib().crd_set_autotune(self._h, int(on)), "crd_set_autotune")
 
-    def set_launch_plan(self, chunk_mode, xcd_mapping, columns_per_lane, nontemporal_stores=0):
+    def set_launch_plan(self, chunk_mode, xcd_mapping, columns_per_lane, nontemporal_stores=0, steps_per_launch=1):
         """Pin the launch plan of the fixed-step kernel (crd_set_launch_plan) instead of having it measured."""
-        self._check(lib().crd_set_launch_plan(self._h, chunk_mode, xcd_mapping, columns_per_lane, nontemporal_stores), "crd_set_launch_plan")
+        self._check(lib().crd_set_launch_plan(self._h, chunk_mode, xcd_mapping, columns_per_lane, nontemporal_stores, steps_per_launch), "crd_set_launch_plan")
 
     def plan_launches(self):
         """Measure the fused step kernel's launch plan now (state not advanced) rather than inside the first step_rk4."""
@@ -383,16 +383,17 @@ def launch_plan_candidates():
         lp = capi.LaunchPlan()
         if lib().crd_launch_plan_candidate(k, C.byref(lp)) != 0:
             return out
-        out.append((lp.one_round, lp.xcd_mapping, lp.columns_per_lane, lp.nontemporal_stores))
+        out.append((lp.one_round, lp.xcd_mapping, lp.columns_per_lane, lp.nontemporal_stores, lp.steps_per_launch))
         k += 1
 
 
 def plan_key(model, precision, plan):
-    """Key of a launch plan in profiles/pmc_traffic.json / profiles/plan_stats.json: plan = (chunk_mode, mapping, columns, nt) or the
-    dict Slab.launch_plan() returns."""
+    """Key of a launch plan in profiles/pmc_traffic.json / profiles/plan_stats.json: plan = (chunk_mode, mapping, columns, nt[, steps per
+    launch]) or the dict Slab.launch_plan() returns."""
     if isinstance(plan, dict):
-        plan = (plan["one_round"], plan["xcd_mapping"], plan["columns_per_lane"], plan["nontemporal_stores"])
-    return "fused/%s/%s/chunk%d/map%d/cols%d/%s" % (model, precision, plan[0], plan[1], plan[2], "nt" if plan[3] else "plain")
+        plan = (plan["one_round"], plan["xcd_mapping"], plan["columns_per_lane"], plan["nontemporal_stores"], plan.get("steps_per_launch", 1))
+    key = "fused/%s/%s/chunk%d/map%d/cols%d/%s" % (model, precision, plan[0], plan[1], plan[2], "nt" if plan[3] else "plain")
+    return key + ("/steps2" if len(plan) > 4 and plan[4] == 2 else "")
 
 
 def rccl_unique_id():

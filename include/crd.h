@@ -432,22 +432,23 @@ typedef struct crd_launch_plan {
 	                           * arithmetic in fp32 */
 	int32_t nontemporal_stores; /* 1: the new state is written with the non-temporal hint (it is not read again by the launch, and
 	                             * does not displace from L2 what neighbouring work items share) */
-	int32_t reserved;
-	double ms_default, ms_chosen; /* measured launch times: plain plan, chosen plan */
+	int32_t steps_per_launch; /* 1; 2: one launch advances the state by TWO RK4 steps (single slabs: the state crosses memory once per two
+	                           * steps, for twice the pipeline registers and a 16-row / 16-column apron); crd_step_rk4 then issues pairs */
+	double ms_default, ms_chosen; /* measured times PER STEP: plain plan, chosen plan */
 } crd_launch_plan;
 int crd_set_autotune(crd_ctx *ctx, int on);
 int crd_get_launch_plan(const crd_ctx *ctx, crd_launch_plan *out);
 /* The plans the measurement chooses among, index 0 .. (first index that returns CRD_EINVAL) - 1: one_round, xcd_mapping,
- * columns_per_lane and nontemporal_stores of *out are set, the rest zero.  (tools/plan_sweep.py profiles every one of them;
+ * columns_per_lane, nontemporal_stores and steps_per_launch of *out are set, the rest zero.  (tools/plan_sweep.py profiles every one of them;
  * tests/test_profiles.py checks that profiles/pmc_traffic.json has an entry for each.) */
 int crd_launch_plan_candidate(int index, crd_launch_plan *out);
-/* Use THIS plan (chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1) for the fixed-step kernel instead of measuring one -- a plan
+/* Use THIS plan (chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1, steps per launch 1..2) for the fixed-step kernel instead of measuring one -- a plan
  * read back from an earlier context of the same shape on the same device (the measurement costs ~0.45 s per context at 8192^2), or
  * a profiling run in which every launch of the kernel should be the plan a previous run chose (`bench.py --launch-plan`).  A pinned
  * plan applies to launches of EVERY size (a measured one only to launches of the height it was measured on).  Where a choice cannot
  * be honoured (two columns per lane on an odd nx, mapping 2 on a launch too short for it) the launch falls back as it would for a
  * measured plan.  crd_get_launch_plan then reports tuned = 1 with both times 0.  CRD_EINVAL outside the ranges. */
-int crd_set_launch_plan(crd_ctx *ctx, int chunk_mode, int xcd_mapping, int columns_per_lane, int nontemporal_stores);
+int crd_set_launch_plan(crd_ctx *ctx, int chunk_mode, int xcd_mapping, int columns_per_lane, int nontemporal_stores, int steps_per_launch);
 /* Measure the plan NOW (a step of the resident state into scratch planes, discarded; the state is not advanced) instead of
  * inside the first crd_step_rk4 -- for callers that time their first steps; also creates the events crd_step_rk4_timed uses.  The
  * measurement is skipped when a plan exists or autotuning is off. */
