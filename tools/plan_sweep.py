@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--steps", type=int, default=24)
     ap.add_argument("--warm", type=int, default=4)
     ap.add_argument("--t-boundary", type=float, default=0.0)
+    ap.add_argument("--plans", default="", help='only these plans: "mode,mapping,cols,nt,steps;..." (default: every candidate)')
     ap.add_argument("--out", default="")
     a = ap.parse_args()
     ny = a.ny or a.size
@@ -34,6 +35,8 @@ def main():
     dt = 0.8 * crd.stable_dt(p)
     y0 = crd.initial_conditions(crd.run_config(p, wave_length=0.1, wave_width=0.5, wave_inside=0))
     plans = crd.launch_plan_candidates()
+    if a.plans:
+        plans = [tuple(int(v) for v in q.split(",")) for q in a.plans.split(";") if q]
     recs = []
     with crd.Slab(p) as slab:
         slab.set_stepper("fused")

@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--trace")
+    ap.add_argument("--counters", help="a counter_collection.csv of any other --pmc pass: every counter in it is averaged per plan")
     a = ap.parse_args()
     meta = json.load(open(a.plans))
     plans, pts = meta["plans"], meta["points"]
@@ -68,6 +69,11 @@ def main():
     for k, r in res.items():
         if "read_bytes_per_point" in r and "write_bytes_per_point" in r:
             r["bytes_per_point"] = r["read_bytes_per_point"] + r["write_bytes_per_point"]
+    if a.counters:
+        names = sorted({r["Counter_Name"] for r in csv.DictReader(open(a.counters)) if "crd_rk4_fused_step_kernel" in r["Kernel_Name"]})
+        for name in names:
+            for k, v in counter(a.counters, name).items():
+                res[k].setdefault("counters", {})[name] = statistics.mean(v)
     if a.trace:
         for k, v in per_plan(plans, step_dispatches(a.trace, lambda r: (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)).items():
             res[k]["trace_us"] = {"avg": statistics.mean(v), "min": min(v), "max": max(v), "launches": len(v)}
