@@ -464,7 +464,14 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 // the apron is 8 columns and 8 rows a side (112 valid columns of 128 with two columns per lane; 16 fill iterations per chunk,
 // hence 64-row chunks), twice the pipeline registers (two or three wavefronts per SIMD instead of four), and the first 16
 // iterations of a chunk run every stage on rows that are not all there yet -- harmless (nothing of them is stored, and the
-// arithmetic has no traps) and cheaper than sixteen specialised prologue iterations in the instruction cache.
+// arithmetic has no traps) and cheaper than sixteen specialised prologue iterations in the instruction cache.  The launch is bound
+// by vector issue, not by memory: the VALU is busy 94 % of it (profiles/r04/sq), so what counts is instructions per useful point.
+// (Tried for that, round 4, and dropped: the BLOCK as the strip -- one apron around four wavefronts' 256 lanes, 240 valid columns
+// instead of 4 x 48, the wavefronts' edge lanes taking their theta neighbours from the wavefront next door through LDS (written
+// one iteration ahead, double-buffered by the iteration's parity, the LDS value entering the DPP shift as its `old` operand so that
+// no instruction merges it).  Bit-identical, 20 % fewer vector instructions per point -- and slower: 0.305 ms per step at 8192^2
+// fp64 against 0.269 (173 VGPRs: two wavefronts per SIMD; held to three, spilling, 0.342), fp32 0.60 against 0.51;
+// profiles/r04/two_step_lds_exchange_ab.txt.)
 // Slot arithmetic: row r of either pipeline lives in slot r mod 4; the second pipeline's rows are the first one's shifted by 4,
 // i.e. the SAME slots -- the stage code is one lambda applied to two sets of arrays.  Per point the arithmetic is the sequence of
 // two single steps exactly (same fused multiply-adds, same constants), so the result is theirs bit for bit.
@@ -788,7 +795,8 @@ constexpr PlanCandidate kPlanCandidates[] = {
     {0, 0, 1, 1}, {0, 1, 1, 1}, {0, 2, 1, 1}, {1, 0, 1, 1}, {1, 1, 1, 1}, {2, 0, 1, 1}, {2, 1, 1, 1}, {2, 2, 1, 1},
     {0, 0, 2, 1}, {0, 1, 2, 1}, {0, 2, 2, 1}, {1, 0, 2, 1}, {1, 1, 2, 1}, {2, 0, 2, 1}, {2, 1, 2, 1}, {2, 2, 2, 1},
     // fifth dimension (round 4): two steps per launch (128-row chunks, or 64), non-temporal stores
-    {0, 0, 1, 1, 2}, {0, 1, 1, 1, 2}, {0, 2, 1, 1, 2}, {2, 1, 1, 1, 2}, {0, 0, 2, 1, 2}, {0, 1, 2, 1, 2}, {0, 2, 2, 1, 2}, {2, 1, 2, 1, 2}};
+    {0, 0, 1, 1, 2}, {0, 1, 1, 1, 2}, {0, 2, 1, 1, 2}, {1, 0, 1, 1, 2}, {1, 1, 1, 1, 2}, {2, 1, 1, 1, 2},
+    {0, 0, 2, 1, 2}, {0, 1, 2, 1, 2}, {0, 2, 2, 1, 2}, {1, 0, 2, 1, 2}, {1, 1, 2, 1, 2}, {2, 1, 2, 1, 2}};
 constexpr int kNumPlanCandidates = (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]);
 
 template <typename Real, int MODEL>

@@ -10,7 +10,7 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import crdmodel_amd as crd  # noqa: E402
 
-for model, prec in (("fhn", "f32"), ("fhn", "f64"), ("goldbeter", "f64")):
+for model, prec in (() if os.environ.get("SKIP_EQ") else (("fhn", "f32"), ("fhn", "f64"), ("goldbeter", "f64"), ("goldbeter", "f32"))):
     p0 = crd.make_params(model, "torus", 700, 80.0, 20.0, 0.12, 1.25 if model == "fhn" else 0.4, ny=300, precision=prec)
     dt = 0.7 * crd.stable_dt(p0)
     p = crd.make_params(model, "torus", 700, 80.0, 20.0, 0.12, 1.25 if model == "fhn" else 0.4, ny=300, precision=prec, t_boundary=6.6 * dt)
@@ -37,7 +37,7 @@ for spec in os.environ.get("SIZES", "fhn:f32:8192:8192,fhn:f64:8192:8192,fhn:f32
     p = crd.make_params(model, "torus", nx, 80.0, 20.0, 0.12, 1.25 if model == "fhn" else 0.4, ny=ny, precision=prec)
     dt = 0.8 * crd.stable_dt(p)
     y0 = crd.initial_conditions(crd.run_config(p, wave_length=0.1, wave_width=0.5))
-    plans = [(0, 0, 1, 1, 1), (0, 1, 2, 1, 1), (0, 2, 2, 1, 1), (0, 0, 1, 1, 2), (0, 1, 1, 1, 2), (0, 2, 1, 1, 2), (0, 0, 2, 1, 2), (0, 1, 2, 1, 2), (0, 2, 2, 1, 2), (2, 0, 2, 1, 2), (2, 1, 2, 1, 2)]
+    plans = [(0, 0, 1, 1, 1), (0, 1, 2, 1, 1), (0, 0, 1, 1, 2), (0, 1, 1, 1, 2), (0, 2, 1, 1, 2), (1, 1, 1, 1, 2), (0, 0, 2, 1, 2), (0, 1, 2, 1, 2), (0, 2, 2, 1, 2), (1, 1, 2, 1, 2)]
     with crd.Slab(p) as slab:
         slab.upload(y0)
         del y0
