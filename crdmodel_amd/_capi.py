@@ -67,7 +67,8 @@ class AdaptiveStats(C.Structure):
     """crd_adaptive_stats"""
 
     _fields_ = [("accepted", C.c_int64), ("rejected", C.c_int64), ("h_last", C.c_double), ("h_next", C.c_double), ("h_min", C.c_double),
-                ("h_max", C.c_double), ("err_last", C.c_double), ("t", C.c_double), ("t_internal", C.c_double), ("h_first", C.c_double)]
+                ("h_max", C.c_double), ("err_last", C.c_double), ("t", C.c_double), ("t_internal", C.c_double), ("h_first", C.c_double),
+                ("launched_ahead", C.c_int64)]
 
 
 class RunConfig(C.Structure):

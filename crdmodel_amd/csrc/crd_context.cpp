@@ -219,7 +219,7 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	CREATE_TRY(hipMalloc(&c->ghost_hi, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc(&c->edge_lo, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc(&c->edge_hi, (size_t)c->nx * c->real_size));
-	CREATE_TRY(hipMalloc((void **)&c->scalar_dev, sizeof(double)));
+	CREATE_TRY(hipMalloc((void **)&c->scalar_dev, 2 * sizeof(double)));
 	CREATE_TRY(hipHostMalloc((void **)&c->scalar_host, 8 * sizeof(double), hipHostMallocPortable | hipHostMallocMapped));
 	if (d0 > 1) {  // theta-blocks: ghost / edge column strips of var0, per stage-input plane and one pair for the AoS RHS
 		const size_t strip = (size_t)c->nyl * c->real_size;
@@ -290,6 +290,8 @@ void crd_destroy(crd_ctx *c)
 	for (hipEvent_t e : c->ev_k) (void)hipEventDestroy(e);
 	for (hipEvent_t e : c->ev_diag) (void)hipEventDestroy(e);
 	if (c->ev_agree) (void)hipEventDestroy(c->ev_agree);
+	for (hipEvent_t e : {c->ev_attempt[0], c->ev_attempt[1], c->ev_norm[0], c->ev_norm[1]})
+		if (e) (void)hipEventDestroy(e);
 	if (c->agree_dev) (void)hipFree(c->agree_dev);
 	if (c->agree_host) (void)hipHostFree(c->agree_host);
 	for (hipEvent_t e : c->ev_band) (void)hipEventDestroy(e);

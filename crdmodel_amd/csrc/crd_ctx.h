@@ -129,8 +129,9 @@ struct crd_ctx {
 	// Where a reduction kernel leaves its scalar for the host: straight in host memory (no copy, one synchronisation) unless the
 	// scalar still has to be reduced over the ranks of an RCCL run on the device.
 	double *scalar_sink() const { return (scalar_host && halo != CRD_HALO_RCCL) ? scalar_host : scalar_dev; }
-	double *err_partials = nullptr;  // adaptive stepping: per-item error sums (lazy)
+	double *err_partials = nullptr;  // adaptive stepping: per-item error sums, two slots of err_capacity (lazy)
 	int err_capacity = 0;
+	hipEvent_t ev_attempt[2] = {nullptr, nullptr}, ev_norm[2] = {nullptr, nullptr};  // ... per slot: kernel done (compute), scalar on the host
 
 	std::shared_ptr<StreamSet> streams;                               // owner of the handles below
 	hipStream_t compute = nullptr, comm = nullptr;

@@ -17,6 +17,7 @@
 // same reason in phi (rows come from the slab's ghost rows, or wrap for a single slab).
 #include <hip/hip_runtime.h>
 
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <type_traits>
@@ -179,6 +180,7 @@ struct FusedArgs {
 	int sw;                   // wavefronts per block = adjacent strips a block covers
 	double *err_partials;     // EMBED: one weighted square sum per work item
 	Real rtol, atol;          // EMBED: error weights 1 / (rtol |y_n| + atol)
+	int err_lo, err_hi;       // EMBED: rows whose error counts (a multi-slab attempt also produces ghost-region rows: the owner counts those)
 };
 
 // EMBED adds a fifth pipeline stage and with it a local error estimate whose weighted square sum
@@ -413,7 +415,7 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 			const int c = p - 5;
 			rhs_point<V, MODEL>(U4[Z5], from_lane_below(U4[Z5]), from_lane_above(U4[Z5]), U4[Z6], U4[Z4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
 			                       ABSORB && a.absorb[4] && boundary_row(c), du, dv);  // k5 at t + dt like k4 (EMBED 1) or at t + 3/4 dt (Zonneveld)
-			if (lane_stores) {  // rows j0 .. j1-1 exactly: stage 5 starts at iteration 10 (row j0) and the loop ends at row j1-1
+			if (lane_stores && c >= a.err_lo && c < a.err_hi) {  // rows j0 .. j1-1 exactly (stage 5 starts at iteration 10, row j0, and the loop ends at row j1-1), owned rows only
 				const V au = __builtin_elementwise_abs(u0[S5]), av = __builtin_elementwise_abs(v0[S5]);
 				const V wu = fmadd((V)a.rtol, au, (V)a.atol), wv = fmadd((V)a.rtol, av, (V)a.atol);
 				V eu, ev;
@@ -841,6 +843,8 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	}
 	a.sw = sw;
 	a.err_partials = c.err_partials;
+	a.err_lo = d.wrap ? INT32_MIN : 0;
+	a.err_hi = d.wrap ? INT32_MAX : d.nyl;
 	a.rtol = (Real)c.rtol;
 	a.atol = (Real)c.atol;
 	// the reaction block of a diffusion-only run is skipped, absorbing rows included (src/GoldbeterModel_torus.cpp:668)

@@ -705,9 +705,13 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 		crd_ctx *c = cs[k];
 		if (!fused_step_supported(c->p.precision, c->desc)) return fail(lead, CRD_EINVAL, "slab too small for the fused step kernel");
 		if (int rc = set_device(c)) return rc;
-		if (!c->err_partials) {
+		if (!c->err_partials) {  // two slots: an attempt and the one launched ahead of its verdict
 			c->err_capacity = std::max(fused_max_items(c->desc), 256);  // (256: the block partials of the initial-step norm)
-			HIP_TRY(c, hipMalloc((void **)&c->err_partials, sizeof(double) * (size_t)c->err_capacity));
+			HIP_TRY(c, hipMalloc((void **)&c->err_partials, 2 * sizeof(double) * (size_t)c->err_capacity));
+			for (int q = 0; q < 2; q++) {
+				HIP_TRY(c, hipEventCreateWithFlags(&c->ev_attempt[q], hipEventDisableTiming));
+				HIP_TRY(c, hipEventCreateWithFlags(&c->ev_norm[q], hipEventDisableTiming));
+			}
 		}
 		if (dense)
 			for (int f = 0; f < 2; f++)
@@ -799,26 +803,76 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	}
 	st.h_first = (arkode_method && A.nst > 0 && A.hprime != A.h) ? A.h * A.eta : h;
 
-	// One attempt of size hh from plane `cur` into plane `dst`: *sum = the weighted square sum of the error estimate over the grid.
-	auto attempt = [&](double hh, int dst, double *sum) -> int {
-		if (multi)  // every attempt starts from freshly exchanged ghost rows of the current state (no overlap: the host waits for the norm anyway)
-			if (int rc = prime_halo(cs, n, cur, kEmbedHalo, true)) return rc;
+	// Ghost rows of each plane's present content that are still valid (multi-slab; a single slab wraps in the kernel).  The
+	// integrator exchanges kAdaptGhost rows of the state it is about to step from when fewer than the attempt's five are left, and
+	// every attempt produces its rows AND the ghost-region rows its input still covers -- the deep halo of the fixed stepper, by
+	// attempts: one exchange per kAdaptGhost / 5 accepted steps instead of one per attempt (a rejected attempt re-runs on the same
+	// input).  Only owned rows count towards the error norm (FusedArgs::err_lo / err_hi), so every rank still sees the same sum.
+	int shortest = lead->nyl;
+	for (int k = 0; k < lead->d1; k++) {
+		int64_t a0, a1;
+		if (crd_slab_extents(lead->g.ny, k, lead->d1, &a0, &a1) == CRD_OK) shortest = (int)std::min<int64_t>(shortest, a1 - a0 + 1);
+	}
+	const int kAdaptGhost = kEmbedHalo * std::max(1, std::min((kGhost - kStepHalo) / kEmbedHalo, shortest / kEmbedHalo));  // 60 rows: 12 attempts
+	int ext_of[crd_ctx::NPLANES];
+	for (int &e : ext_of) e = multi ? 0 : (1 << 20);
+	// One attempt of size hh at time tt from plane `src` into plane `dst`, enqueued only: the kernel, the fixed-order sum of its
+	// partials, and -- on the second stream, behind an event -- the reduction over the ranks and the copy of the scalar to
+	// page-locked memory.  `slot` (0 / 1) names the buffers; finish_attempt(slot) waits for the scalar.
+	auto launch_attempt = [&](double tt, double hh, int src, int dst, int slot) -> int {
+		if (ext_of[src] < kEmbedHalo) {
+			if (int rc = prime_halo(cs, n, src, kAdaptGhost, true)) return rc;
+			for (int k = 0; k < n; k++) {
+				if (int rc = set_device(cs[k])) return rc;
+				HIP_TRY(cs[k], hipStreamWaitEvent(cs[k]->compute, cs[k]->ev_halo, 0));
+			}
+			ext_of[src] = kAdaptGhost;
+		}
+		const int e = multi ? ext_of[src] - kEmbedHalo : 0;
 		for (int k = 0; k < n; k++) {
 			crd_ctx *c = cs[k];
 			if (int rc = set_device(c)) return rc;
-			FusedCall call = make_fused_call(c, t, hh, cur, dst);
+			FusedCall call = make_fused_call(c, tt, hh, src, dst);
 			call.embed = arkode_method ? 2 : 1;
-			call.absorb[4] = arkode_method ? (absorbing(c, t + 0.75 * hh) ? 1 : 0) : call.absorb[3];  // the fifth stage's time: t + 3/4 h (Zonneveld) / t + h
+			call.absorb[4] = arkode_method ? (absorbing(c, tt + 0.75 * hh) ? 1 : 0) : call.absorb[3];  // the fifth stage's time: t + 3/4 h (Zonneveld) / t + h
 			call.plan = arkode_method ? &c->plan_arkode : &c->plan_embed;
 			call.rtol = o.rtol;
 			call.atol = o.atol;
-			call.err_partials = c->err_partials;
+			call.err_partials = c->err_partials + (size_t)slot * (size_t)c->err_capacity;
 			call.err_capacity = c->err_capacity;
-			call.err_sum = c->scalar_sink();
-			if (multi) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
-			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
+			const bool reduce_on_device = c->halo == CRD_HALO_RCCL;
+			// (the slot's previous user may have been launched ahead and never waited for: its reduction on the second stream must be
+			// through with the slot's device scalar before this attempt's sum lands there)
+			if (reduce_on_device) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_norm[slot], 0));
+			call.err_sum = reduce_on_device ? c->scalar_dev + slot : c->scalar_host + slot;  // (the sum kernel writes page-locked memory directly unless ranks still have to be added)
+			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -e, c->nyl + e, 0, 0, c->compute));
+			if (reduce_on_device) {
+				HIP_TRY(c, hipEventRecord(c->ev_attempt[slot], c->compute));
+				HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_attempt[slot], 0));
+				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev + slot, c->scalar_dev + slot, 1, ncclDouble, ncclSum, c->nccl, c->comm));  // (every rank gets the same bits, hence takes the same decision)
+				HIP_TRY(c, hipMemcpyAsync(c->scalar_host + slot, c->scalar_dev + slot, sizeof(double), hipMemcpyDeviceToHost, c->comm));
+				HIP_TRY(c, hipEventRecord(c->ev_norm[slot], c->comm));
+			} else {
+				HIP_TRY(c, hipEventRecord(c->ev_norm[slot], c->compute));
+			}
 		}
-		return collect_scalar(cs, n, false, sum);  // (RCCL: every rank gets the same bits, hence takes the same decision)
+		ext_of[dst] = multi ? e : (1 << 20);
+		return CRD_OK;
+	};
+	auto finish_attempt = [&](int slot, double *sum) -> int {
+		double acc = 0.0;
+		for (int k = 0; k < n; k++) {  // (LOCAL groups: the slabs' sums added on the host in slab order)
+			crd_ctx *c = cs[k];
+			if (int rc = set_device(c)) return rc;
+			HIP_TRY(c, hipEventSynchronize(c->ev_norm[slot]));
+			acc += c->scalar_host[slot];
+		}
+		*sum = acc;
+		return CRD_OK;
+	};
+	auto attempt = [&](double hh, int dst, double *sum) -> int {  // launch and wait (the RK4(3) pair's loop)
+		if (int rc = launch_attempt(t, hh, cur, dst, 0)) return rc;
+		return finish_attempt(0, sum);
 	};
 	auto accept_planes = [&](int dst) {  // rotate: the old state becomes y_n (kept for the interpolant), the old y_n / scratch becomes the next target
 		const int old_cur = cur;
@@ -835,6 +889,12 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	bool after_reject = false;
 	int rc = CRD_OK;
 	int64_t steps_this_call = 0;
+	struct {
+		bool live;
+		double h;
+		int src, dst, slot;
+	} ahead = {false, 0.0, -1, -1, 0};  // the attempt launched ahead of its predecessor's verdict (CRD_ADAPT_ARKODE)
+	int next_slot = 0;
 	while (t < tout && rc == CRD_OK && arkode_method) {
 		// ---- CRD_ADAPT_ARKODE: one step = attempts until the error test passes (arkStep), then arkPrepareNextStep / arkCompleteStep ----
 		if (steps_this_call >= o.max_steps) {
@@ -849,11 +909,35 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 		const int dst = spare;
 		double dsm = 0.0;
 		for (int nef = 0;;) {
+			// This attempt -- unless it is already in flight: the previous step launched it ahead of its own verdict (below).
+			int my_slot;
+			if (ahead.live && ahead.h == A.h && ahead.src == cur && ahead.dst == dst) {
+				my_slot = ahead.slot;
+				st.launched_ahead++;
+			} else {
+				my_slot = next_slot;
+				next_slot ^= 1;
+				if ((rc = launch_attempt(t, A.h, cur, dst, my_slot))) break;
+			}
+			ahead.live = false;
+			// The step after this one, launched BEFORE this one's error norm is known, on the assumption the integrator makes most of
+			// the time on these grids: the attempt passes and the step size stays (the controller's dead band, or the cap).  If that
+			// turns out wrong the launch is void -- it wrote a plane nobody needs (the one that becomes scratch once this step is
+			// accepted; if this step is rejected, y_{n-1} in it is not needed either: the interpolant is built on the LAST step) --
+			// and the next attempt is simply issued afresh.  The host's wait for the norm (reduction over the ranks, copy, wake-up)
+			// then hides under a kernel that is already running.  No exchange is ever issued ahead.
+			const int after = prev >= 0 ? prev : third;
+			if (after >= 0 && t + A.h < tout && steps_this_call + 1 < o.max_steps && ext_of[dst] >= kEmbedHalo) {
+				if ((rc = launch_attempt(t + A.h, A.h, dst, after, next_slot))) break;
+				ahead = {true, A.h, dst, after, next_slot};
+				next_slot ^= 1;
+			}
 			double sum = 0.0;
-			if ((rc = attempt(A.h, dst, &sum))) break;
+			if ((rc = finish_attempt(my_slot, &sum))) break;
 			dsm = std::sqrt(sum / n_components);
 			st.err_last = dsm;
 			if (dsm <= 1.0) break;  // (a NaN fails the test)
+			ahead.live = false;     // a failed step: what was launched ahead of it is void
 			nef++;
 			st.rejected++;
 			if (nef == arkode::kMaxNef) {
@@ -934,6 +1018,10 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			after_reject = true;
 			h = hh * std::fmin(eta, 0.9);
 		}
+	}
+	if (ahead.live) {  // (cannot happen -- nothing is launched ahead of the last step -- but a void launch must never outlive the call)
+		double ignored;
+		(void)finish_attempt(ahead.slot, &ignored);
 	}
 	st.t_internal = t;
 	if (rc == CRD_OK && dense && prev >= 0 && t >= tout) {

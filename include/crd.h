@@ -313,9 +313,10 @@ int crd_synchronize(crd_ctx *ctx);
  * step at tout, built from y_n, y_{n+1}, f(t_n, y_n), f(t_{n+1}, y_{n+1}) (ARKode's default dense output is of degree 3 too), and
  * the integrator's own state stays at its internal time (stats.t_internal >= tout): the next call with t0 equal to this call's
  * tout continues from there.  Any other call that changes the state (upload, fixed-step stepping, a different t0) drops it.
- * Multi-slab runs exchange five ghost rows before
- * every attempt and reduce the norm over the ring (ncclAllReduce; LOCAL groups add the slabs' sums on the host in slab
- * order), so every rank takes the same decisions.  h0 = 0 starts from the diffusion-stability step; by default steps are
+ * Multi-slab runs exchange 60 ghost rows of the state every twelve
+ * accepted steps (each attempt also produces the ghost-region rows its input still covers: the fixed stepper's deep halo, by
+ * attempts) and reduce the norm of the OWNED rows over the ring (ncclAllReduce; LOCAL groups add the slabs' sums on the host in
+ * slab order), so every rank takes the same decisions.  h0 = 0 starts from the diffusion-stability step; by default steps are
  * also capped at that bound (h_max = 0), which removes the reject / regrow cycle of a stability-limited explicit method. */
 /* Which embedded pair and controller crd_integrate_adaptive runs. */
 enum {
@@ -356,6 +357,8 @@ typedef struct crd_adaptive_stats {
 	double t;               /* time of the state handed back (== tout on success) */
 	double t_internal;      /* time the integrator itself has reached: == t without dense output, >= t with it */
 	double h_first;         /* size of the first step this call attempted (on a fresh state under CRD_ADAPT_ARKODE: the arkHin estimate) */
+	int64_t launched_ahead; /* attempts that were already running when their predecessor's error norm arrived (CRD_ADAPT_ARKODE launches the next
+	                         * step ahead of the verdict, assuming "accepted, same size"; a wrong guess costs one discarded launch) */
 } crd_adaptive_stats;
 int crd_adaptive_defaults(crd_adaptive_options *opt);
 int crd_integrate_adaptive(crd_ctx *ctx, double t0, double tout, const crd_adaptive_options *opt, crd_adaptive_stats *stats);
