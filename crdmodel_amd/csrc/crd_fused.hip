@@ -624,8 +624,12 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 // (src/FHNmodel_torus.cpp:643-653) run the body with the selects, all others the body without (see fused_item).
 // EMBED, COLS, NT: see FusedArgs / fused_item above.
 // STEPS = 2: two steps per launch (fused_item_two_steps).
+// (Its FHN instantiations are held to three wavefronts per SIMD -- HIP's second launch bound is the minimum number of wavefronts per
+// SIMD: the select-free body needs exactly the 168 VGPRs that allows, the body with the absorbing-row selects three more, and the
+// ABSORB kernel, which holds both, would otherwise run ALL its items at two wavefronts per SIMD: +20 % on a run with tBoundary > 0.)
 template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false, int STEPS = 1>
-__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
+__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock, (STEPS == 2 && MODEL == CRD_MODEL_FHN && !(COLS == 2 && sizeof(Real) == 8)) ? 3 : 1)
+    crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
 	static_assert(STEPS == 1 || (STEPS == 2 && EMBED == 0), "two steps per launch: the plain step only");
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the

@@ -1,0 +1,35 @@
+# Round-4 record: the GPU suite, the driver-style bench line, every BASELINE configuration through bench.py, the self-ring share,
+# bench.py's LOCAL-transport leg rehearsed with two slabs on the one device, the sweeps of every launch plan (PMC traffic + kernel
+# trace) and `rocprofv3 --stats` of bench.py with every plan pinned.  Lands in gpurun_out/r04/final/ and gpurun_out/r04/{sweep,plan_stats}/.
+set -x
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04/final; mkdir -p $OUT
+cd $R
+timeout -k 10 900 python3 -m pytest tests -m gpu -x -q > $OUT/pytest_gpu.log 2>&1; echo "pytest rc $?" | tee -a $OUT/pytest_gpu.log; tail -4 $OUT/pytest_gpu.log
+b() { name=$1; shift; timeout -k 10 300 python3 bench.py "$@" > $OUT/bench_$name.json 2> $OUT/bench_$name.err || echo "bench $name failed"; python3 - $OUT/bench_$name.json <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r, lp = d["roofline"], d["config"]["launch_plan"]
+    print("%-28s %.4f ms/step  %.3e pt-steps/s  frac %.3f frac_wall %.3f  traffic %s  plan %s" % (sys.argv[1].split("bench_")[-1][:-5], d["ms_per_step"], d["value"], r["frac"], r["frac_wall"],
+          ("%.2f B/pt" % (r["traffic"] / (r["algorithmic_bytes_per_launch"] / (32 if d["dtype"] == "f64" else 16)))) if r.get("traffic") else None, r.get("plan_key")))
+except Exception as e:
+    print("no line:", sys.argv[1], e)
+PY
+}
+b driver_style --steps 20 --warmup 5
+b c3_fhn_8192_f64 --steps 200 --warmup 20
+b c3_absorbing_rows_on --steps 200 --warmup 20 --t-boundary 1e9 --no-cpu-baseline --staged-steps 0
+b c3_one_step_per_launch --steps 200 --warmup 20 --launch-plan 0,1,1,1,1 --no-cpu-baseline --staged-steps 0
+b c3_one_step_absorbing --steps 200 --warmup 20 --launch-plan 0,1,1,1,1 --t-boundary 1e9 --no-cpu-baseline --staged-steps 0
+b c2_fhn_4096_f64 --size 4096 --steps 200 --warmup 20 --no-cpu-baseline
+b c4_goldbeter_4096_f64 --size 4096 --model goldbeter --steps 200 --warmup 20 --no-cpu-baseline
+b goldbeter_8192_f64 --model goldbeter --steps 200 --warmup 20 --no-cpu-baseline --staged-steps 0
+b c5_fhn_16384_f32 --size 16384 --precision f32 --steps 100 --warmup 20 --no-cpu-baseline --staged-steps 0
+b fhn_8192_f32 --precision f32 --steps 200 --warmup 20 --no-cpu-baseline --staged-steps 0
+b staged_8192 --stepper staged --steps 40 --warmup 5 --no-cpu-baseline
+b selfring_8192 --force-rccl --steps 200 --warmup 20 --no-cpu-baseline --staged-steps 0
+b local_two_slabs_one_device --gpus 2 --transport local --devices 0,0 --steps 100 --warmup 10 --no-cpu-baseline
+NYS=1024 STEPS=400 ROUNDS=5 VARIANTS="self,rccl,rccl:e16,rccl:s2,rccl:e16s2" timeout -k 10 300 python3 tools/ring_overhead.py > $OUT/ring_overhead_8192x1024.txt 2>&1; grep median $OUT/ring_overhead_8192x1024.txt
+NX=16384 NYS=2048 PRECISION=f32 STEPS=200 ROUNDS=3 VARIANTS="self,rccl,rccl:e16" timeout -k 10 300 python3 tools/ring_overhead.py > $OUT/ring_overhead_16384x2048_f32.txt 2>&1; grep median $OUT/ring_overhead_16384x2048_f32.txt
+bash tools/jobs/r04_sweep.sh "fhn f64 8192" "goldbeter f64 4096" "fhn f32 16384" > $OUT/sweep_job.log 2>&1 || tail -5 $OUT/sweep_job.log
+bash tools/jobs/r04_plan_stats.sh > $OUT/plan_stats_job.log 2>&1; tail -2 $OUT/plan_stats_job.log | cut -c1-200

@@ -32,6 +32,7 @@ with open(rows_path, "w") as rows:
         if r.returncode != 0 or line is None or not stats:
             print("FAILED", key, r.returncode, r.stderr[-500:], flush=True)
             continue
+        best = None
         for row in csv.DictReader(open(stats[0])):
             if "crd_rk4_fused_step_kernel" in row["Name"]:
                 if not header_done:
@@ -39,8 +40,13 @@ with open(rows_path, "w") as rows:
                     header_done = True
                 rows.write(key + "," + ",".join('"%s"' % v if "," in v else v for v in row.values()) + "\n")
                 rows.flush()
+                if best is None or int(row["Calls"]) > int(best["Calls"]):  # (a two-step plan also has a one-step row: an odd last step)
+                    best = row
+        if best is not None:
+            row = best
+            if True:
                 recs[key] = {"bench_stats_avg_us": float(row["AverageNs"]) / 1e3, "bench_stats_min_us": float(row["MinNs"]) / 1e3, "bench_stats_max_us": float(row["MaxNs"]) / 1e3,
-                             "bench_stats_calls": int(row["Calls"]), "bench_kernel_ms_events": line["roofline"]["kernel_ms"], "bench_ms_per_step": line["ms_per_step"],
+                             "bench_stats_calls": int(row["Calls"]), "bench_stats_kernel": row["Name"].split("(")[0].replace("void crd::(anonymous namespace)::", ""), "bench_kernel_ms_events": line["roofline"]["kernel_ms"], "bench_ms_per_step": line["ms_per_step"],
                              "bench_frac": line["roofline"]["frac"], "bench_frac_wall": line["roofline"]["frac_wall"], "bench_value": line["value"],
                              "bench_command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --staged-steps 0 --launch-plan %s %s"
                                               % (",".join(str(v) for v in plan), " ".join(extra)),
