@@ -17,6 +17,7 @@
 // same reason in phi (rows come from the slab's ghost rows, or wrap for a single slab).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -514,12 +515,23 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		j -= (j >= s.nyl) ? wrap_nyl : 0;
 		return (ptrdiff_t)j * nx;
 	};
-	auto boundary_row = [&](int j) -> bool {
-		int gj = a.js + j;
-		if (gj < 0) gj += a.ny;
-		else if (gj >= a.ny) gj -= a.ny;
-		return gj == 0 || gj == a.ny - 1;
-	};
+	// Global phi boundary rows (src/FHNmodel_torus.cpp:643-653).  Rows ny - 1 and 0 are neighbours on the periodic grid: within the rows
+	// this item's pipeline touches (fewer than 2 ny of them) they are local rows jb, jb + 1 and possibly jb + ny, jb + ny + 1.  Two
+	// scalars and a bit mask of the eight stage flags instead of js, ny and eight flag words: the body with the selects must not need
+	// more registers than the one without (168 VGPRs = three wavefronts per SIMD), or the launch's kernel, which holds both, runs
+	// every item at two.
+	int jb = 0, amask = 0;
+	if (ABSORB) {
+		int g0 = (a.js + jbase) % a.ny;  // global row of the first row the pipeline takes
+		if (g0 < 0) g0 += a.ny;
+		jb = jbase + (a.ny - 1 - g0);
+#pragma unroll
+		for (int k = 0; k < 4; k++) amask |= (a.absorb[k] ? 1 << k : 0) | (a.absorb2[k] ? 16 << k : 0);
+		jb = __builtin_amdgcn_readfirstlane(jb);
+		amask = __builtin_amdgcn_readfirstlane(amask);
+	}
+	const int ny_rows = a.ny;
+	auto boundary_row = [&](int j) -> bool { return (unsigned)(j - jb) <= 1u || (unsigned)(j - jb - ny_rows) <= 1u; };
 
 	struct Pipe {
 		V u0[M], v0[M], U1[M], U2[M], U3[M], V1[2], V2[2], V3[2], aU[M], aV[M];
@@ -550,31 +562,31 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	Real *out_row_u = a.out_u + (ptrdiff_t)(jbase - 2 * kApron) * nx, *out_row_v = a.out_v + (ptrdiff_t)(jbase - 2 * kApron) * nx;
 
 	// Stages 1..4 of one step on the pipeline P whose newest row is `p` (slot S0): new state of row p - 4 in (nu, nv).
-	// absorb: the step's four stage flags; b4: b(j) of row p - 4 (read by the caller before row p took over its slot).
-	auto stages = [&](Pipe &P, const int p, auto kk, const int *absorb, const Real b4, V &nu, V &nv) {
+	// flag_bit: where the step's four stage flags start in amask; b4: b(j) of row p - 4 (read by the caller before row p took over its slot).
+	auto stages = [&](Pipe &P, const int p, auto kk, const int flag_bit, const Real b4, V &nu, V &nv) {
 		constexpr int K = decltype(kk)::value;
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M, S5 = (K + 2 * M - 5) % M;
 		V du, dv;
 		rhs_point<V, MODEL>(P.u0[S1], from_lane_below(P.u0[S1]), from_lane_above(P.u0[S1]), P.u0[S2], P.u0[S0], P.v0[S1], cA, cX, cP, P.bq[S1], ka4,
-		                       ABSORB && absorb[0] && boundary_row(p - 1), du, dv);
+		                       ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), du, dv);
 		P.U1[S1] = fmadd(h2, du, P.u0[S1]);
 		P.V1[S1 & 1] = fmadd(h2, dv, P.v0[S1]);
 		P.aU[S1] = fmadd(h6, du, P.u0[S1]);
 		P.aV[S1] = fmadd(h6, dv, P.v0[S1]);
 		rhs_point<V, MODEL>(P.U1[S2], from_lane_below(P.U1[S2]), from_lane_above(P.U1[S2]), P.U1[S3], P.U1[S1], P.V1[S2 & 1], cA, cX, cP, P.bq[S2], ka4,
-		                       ABSORB && absorb[1] && boundary_row(p - 2), du, dv);
+		                       ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), du, dv);
 		P.U2[S2] = fmadd(h2, du, P.u0[S2]);
 		P.V2[S2 & 1] = fmadd(h2, dv, P.v0[S2]);
 		P.aU[S2] = fmadd(h3, du, P.aU[S2]);
 		P.aV[S2] = fmadd(h3, dv, P.aV[S2]);
 		rhs_point<V, MODEL>(P.U2[S3], from_lane_below(P.U2[S3]), from_lane_above(P.U2[S3]), P.U2[S4], P.U2[S2], P.V2[S3 & 1], cA, cX, cP, P.bq[S3], ka4,
-		                       ABSORB && absorb[2] && boundary_row(p - 3), du, dv);
+		                       ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), du, dv);
 		P.U3[S3] = fmadd(h1, du, P.u0[S3]);
 		P.V3[S3 & 1] = fmadd(h1, dv, P.v0[S3]);
 		P.aU[S3] = fmadd(h3, du, P.aU[S3]);
 		P.aV[S3] = fmadd(h3, dv, P.aV[S3]);
 		rhs_point<V, MODEL>(P.U3[S4], from_lane_below(P.U3[S4]), from_lane_above(P.U3[S4]), P.U3[S5], P.U3[S3], P.V3[S4 & 1], cA, cX, cP, b4, ka4,
-		                       ABSORB && absorb[3] && boundary_row(p - 4), du, dv);
+		                       ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), du, dv);
 		nu = fmadd(h6, du, P.aU[S4]);
 		nv = fmadd(h6, dv, P.aV[S4]);
 	};
@@ -597,11 +609,11 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 			jn = (jn < jlast) ? jn + 1 : jlast;
 		}
 		V nu, nv;
-		stages(A, p, kk, a.absorb, b4a, nu, nv);  // step n: the new row p - 4 ...
+		stages(A, p, kk, 0, b4a, nu, nv);  // step n: the new row p - 4 ...
 		B.u0[S0] = nu;                            // ... is the second pipeline's newest row (same slot: rows shifted by 4)
 		B.v0[S0] = nv;
 		B.bq[S0] = b4a;
-		stages(B, p - kApron, kk, a.absorb2, b4b, nu, nv);  // step n + 1: the new row p - 8
+		stages(B, p - kApron, kk, 4, b4b, nu, nv);  // step n + 1: the new row p - 8
 		if (m >= 4 * kApron && lane_stores) {  // rows j0 .. j1 - 1 exactly
 			row_store<NT>(at_lane_as<V>(out_row_u, ob), nu);
 			row_store<NT>(at_lane_as<V>(out_row_v, ob), nv);
@@ -624,12 +636,8 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 // (src/FHNmodel_torus.cpp:643-653) run the body with the selects, all others the body without (see fused_item).
 // EMBED, COLS, NT: see FusedArgs / fused_item above.
 // STEPS = 2: two steps per launch (fused_item_two_steps).
-// (Its FHN instantiations are held to three wavefronts per SIMD -- HIP's second launch bound is the minimum number of wavefronts per
-// SIMD: the select-free body needs exactly the 168 VGPRs that allows, the body with the absorbing-row selects three more, and the
-// ABSORB kernel, which holds both, would otherwise run ALL its items at two wavefronts per SIMD: +20 % on a run with tBoundary > 0.)
 template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false, int STEPS = 1>
-__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock, (STEPS == 2 && MODEL == CRD_MODEL_FHN && !(COLS == 2 && sizeof(Real) == 8)) ? 3 : 1)
-    crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
+__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
 	static_assert(STEPS == 1 || (STEPS == 2 && EMBED == 0), "two steps per launch: the plain step only");
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
@@ -859,6 +867,36 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 
 	int cols = cols_default, steps = 1;
 	bool nt = false;
+	// The launch's geometry in two layers: configure() fixes the plan's choices, layout() cuts the rows in R -- the caller's, or
+	// a part of them (fire() below) -- into items accordingly.
+	int R[4] = {row_begin, row_end, row_begin2, row_end2}, plan_mode = 0, plan_remap = 0, chunk_override = 0;
+	auto layout = [&]() {
+		const int rows_a = R[1] - R[0], rows_b = R[3] - R[2];
+		const int nsb = (a.nstrips + sw - 1) / sw;
+		a.chunk = chunk_override > 0 ? std::min(chunk_override, rows_a + rows_b) : fused_chunk_rows<Real, MODEL>(a.nstrips, rows_a + rows_b, plan_mode, cols, steps);
+		const int n1 = (rows_a + a.chunk - 1) / a.chunk, n2 = (rows_b + a.chunk - 1) / a.chunk;
+		a.nchunks = n1 + n2;
+		a.first2 = n2 > 0 ? n1 : a.nchunks;
+		a.r_begin[0] = R[0];
+		a.r_end[0] = R[1];
+		a.r_begin[1] = R[2];
+		a.r_end[1] = R[3];
+		a.nitems = a.nstrips * a.nchunks;
+		a.nblocks = nsb * a.nchunks;
+		a.remap = plan_remap;
+		if (const char *e = tuning::knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);
+		a.xs_lanes = 1;
+		if (a.remap == 2) {
+			const int per_xcd = resident_wavefronts<Real, MODEL>(cols, steps) / sw / kNumXcd;
+			if (rows_b > 0 || a.nchunks < 2 * kNumXcd || per_xcd < nsb) {
+				a.remap = 0;  // two row ranges, or too few chunks / slots for lanes: plain order
+			} else {
+				a.xs_lanes = per_xcd / nsb;
+				const int most = (a.nchunks + kNumXcd - 1) / kNumXcd;  // chunks of the best-served XCD
+				a.nblocks = kNumXcd * ((most + a.xs_lanes - 1) / a.xs_lanes) * nsb * a.xs_lanes;
+			}
+		}
+	};
 	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0, int want_steps = 1) {
 		steps = (want_steps == 2 && kCanTwoSteps) ? 2 : 1;
 		nt = want_nt != 0;
@@ -867,30 +905,9 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
 		const int valid = cols * kLanes - 2 * steps * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
 		a.nstrips = (d.nx + valid - 1) / valid;
-		const int nsb = (a.nstrips + sw - 1) / sw;
-		a.chunk = fused_chunk_rows<Real, MODEL>(a.nstrips, rows + rows2, one_round, cols, steps);
-		const int n1 = (rows + a.chunk - 1) / a.chunk, n2 = (rows2 + a.chunk - 1) / a.chunk;
-		a.nchunks = n1 + n2;
-		a.first2 = n2 > 0 ? n1 : a.nchunks;
-		a.r_begin[0] = row_begin;
-		a.r_end[0] = row_end;
-		a.r_begin[1] = row_begin2;
-		a.r_end[1] = row_end2;
-		a.nitems = a.nstrips * a.nchunks;
-		a.nblocks = nsb * a.nchunks;
-		a.remap = remap;
-		if (const char *e = tuning::knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);
-		a.xs_lanes = 1;
-		if (a.remap == 2) {
-			const int per_xcd = resident_wavefronts<Real, MODEL>(cols, steps) / sw / kNumXcd;
-			if (rows2 > 0 || a.nchunks < 2 * kNumXcd || per_xcd < nsb) {
-				a.remap = 0;  // two row ranges, or too few chunks / slots for lanes: plain order
-			} else {
-				a.xs_lanes = per_xcd / nsb;
-				const int most = (a.nchunks + kNumXcd - 1) / kNumXcd;  // chunks of the best-served XCD
-				a.nblocks = kNumXcd * ((most + a.xs_lanes - 1) / a.xs_lanes) * nsb * a.xs_lanes;
-			}
-		}
+		plan_mode = one_round;
+		plan_remap = remap;
+		layout();
 	};
 	auto fire = [&]() -> hipError_t {
 		if (c.embed) {
@@ -928,8 +945,62 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (nt) with_cols(absorb_c, std::true_type{});
 				else with_cols(absorb_c, std::false_type{});
 			};
-			if (steps == 2 ? absorb12 : absorb1) with_nt(std::true_type{});
-			else with_nt(std::false_type{});
+			auto launch = [&](bool with_selects) {
+				if (with_selects) with_nt(std::true_type{});
+				else with_nt(std::false_type{});
+			};
+			if (steps == 2 && absorb12) {
+				// Two steps per launch with absorbing rows on.  The ABSORB kernel holds the body with the selects AND the one without
+				// (it decides per chunk), and the former's scalar registers spill into two vector registers of the whole kernel: 170
+				// VGPRs, two wavefronts per SIMD instead of three for EVERY item of the launch (+20 ... 38 % measured).  So the rows are
+				// cut: those whose pipeline can meet a global boundary row -- within 2 kApron rows of rows ny - 1 / 0, a band of 18 --
+				// go out first as a launch of their own (ABSORB kernel, 3-row items: it is the items' length, not their number, that
+				// sets such a launch's duration), the rest as launches of the select-free kernel.  Same arithmetic, same bits.
+				const int want[4] = {R[0], R[1], R[2], R[3]};
+				int with_sel[4][2], without[6][2], n_with = 0, n_without = 0;
+				bool fits = true;
+				for (int r = 0; r < 2 && fits; r++) {
+					int cursor = want[2 * r];
+					const int end = want[2 * r + 1];
+					for (int g = -1; g <= 1 && cursor < end; g++) {  // local rows of global rows ny - 1 and 0, one period down / here / one up
+						const int jb = (ny - 1 - js) + g * ny, lo = std::max(cursor, jb - 2 * kApron), hi = std::min(end, jb + 2 + 2 * kApron);
+						if (lo >= hi) continue;
+						if (cursor < lo) {
+							if (n_without == 6) fits = false;
+							else without[n_without][0] = cursor, without[n_without++][1] = lo;
+						}
+						if (n_with == 4) fits = false;
+						else with_sel[n_with][0] = lo, with_sel[n_with++][1] = hi;
+						cursor = hi;
+					}
+					if (cursor < end) {
+						if (n_without == 6) fits = false;
+						else without[n_without][0] = cursor, without[n_without++][1] = end;
+					}
+				}
+				if (!fits || n_with == 0) {
+					launch(true);
+				} else {
+					auto issue = [&](int (*piece)[2], int count, bool selects, int item_rows) {
+						for (int q = 0; q < count; q += 2) {
+							R[0] = piece[q][0];
+							R[1] = piece[q][1];
+							R[2] = q + 1 < count ? piece[q + 1][0] : 0;
+							R[3] = q + 1 < count ? piece[q + 1][1] : 0;
+							chunk_override = item_rows;
+							layout();
+							launch(selects);
+						}
+					};
+					issue(with_sel, n_with, true, 3);
+					issue(without, n_without, false, 0);
+					for (int q = 0; q < 4; q++) R[q] = want[q];
+					chunk_override = 0;
+					layout();
+				}
+			} else {
+				launch(steps == 2 ? absorb12 : absorb1);
+			}
 		}
 		return launch_status();
 	};
