@@ -770,10 +770,27 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols, int steps 
 	if (chunk == 8 && (long)((nstrips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + 7) / 8) < device_cus() / 2) chunk = 4;
 	if (const char *e = tuning::knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
 	if (steps == 1 && chunk_mode == 2 && chunk == 32 && (long)nstrips * ((rows + 63) / 64) >= 2L * slots) chunk = 64;  // fewer apron rows recomputed: pays where fp64 issue binds (Goldbeter)
-	if (one_round) {
+	if (one_round && steps == 1) {
 		const long strip_blocks = (nstrips + kWavesPerBlock - 1) / kWavesPerBlock, fit = (slots / kWavesPerBlock) / strip_blocks;
 		const long need = fit >= 1 ? (rows + fit - 1) / fit : 0;
-		if (need > chunk && need <= 96 * steps) chunk = (int)need;  // (two steps per launch: up to 192 rows)
+		if (need > chunk && need <= 96) chunk = (int)need;
+	}
+	if (one_round && steps == 2) {
+		// Two steps per launch are bound by issue, and what a launch loses is its last, partly filled round of resident blocks: chunks
+		// such that the launch is just under a WHOLE NUMBER of rounds -- the fewest rounds whose chunks stay within 288 rows (longer
+		// ones have fewer fill rows per row; 8192^2 fp64: 128 rows = 3.6 rounds 0.2667 ms per step, 155 = 2.97 rounds 0.2617, 235 =
+		// 1.96 rounds 0.2618, but 161 = 2.86 rounds 0.2669 and 241 = 1.90 rounds 0.2697; 16384^2 fp32: 128 rows 0.4948, 274 rows 0.4830;
+		// a rank's share of 1024 rows: one round of 61 rows; profiles/r04/whole_rounds.txt).
+		const long strip_blocks = (nstrips + kWavesPerBlock - 1) / kWavesPerBlock, resident_blocks = slots / kWavesPerBlock;
+		for (long k = 1; k <= 8; k++) {
+			const long chunks = k * resident_blocks / strip_blocks;
+			if (chunks < 1) continue;
+			const long need = (rows + chunks - 1) / chunks;
+			if (need <= 288) {
+				if (need >= 16) chunk = (int)need;
+				break;
+			}
+		}
 	}
 	if (const char *e = tuning::knob("CRD_FUSED_CHUNK")) {  // tuning knob
 		const int v = std::atoi(e);

@@ -16,7 +16,8 @@ for case in os.environ.get("CASES", "f64:1:8192:8192,f32:2:8192:8192").split(","
     p = crd.make_params(model, "torus", int(nx), 80.0, 20.0, 0.12, 1.25 if model == "fhn" else 0.4, ny=int(ny), precision=prec)
     dt = 0.8 * crd.stable_dt(p)
     y0 = crd.initial_conditions(crd.run_config(p, wave_length=0.1, wave_width=0.5))
-    variants = [(steps, chunk, remap) for steps in (1, 2) for chunk in ((32,) if steps == 1 else (48, 64, 96, 128, 192, 256)) for remap in (0, 1, 2)]
+    chunks = [int(v) for v in os.environ.get("CHUNKS", "48,64,96,128,192,256").split(",")]
+    variants = [(steps, chunk, remap) for steps in (1, 2) for chunk in ((32,) if steps == 1 else chunks) for remap in [int(v) for v in os.environ.get("REMAPS", "0,1,2").split(",")]]
     with crd.Slab(p) as slab:
         slab.upload(y0)
         del y0
