@@ -5,7 +5,7 @@ set -x
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out/r04/plan_stats; mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
 python3 - "$@" <<'PY'
-import csv, glob, json, os, subprocess, sys, shutil
+import csv, glob, json, os, re, subprocess, sys, shutil
 R = os.environ["GRAFT_REPO_ROOT"]
 sys.path.insert(0, R)
 import crdmodel_amd as crd
@@ -46,7 +46,7 @@ with open(rows_path, "w") as rows:
             row = best
             if True:
                 recs[key] = {"bench_stats_avg_us": float(row["AverageNs"]) / 1e3, "bench_stats_min_us": float(row["MinNs"]) / 1e3, "bench_stats_max_us": float(row["MaxNs"]) / 1e3,
-                             "bench_stats_calls": int(row["Calls"]), "bench_stats_kernel": row["Name"].split("(")[0].replace("void crd::(anonymous namespace)::", ""), "bench_kernel_ms_events": line["roofline"]["kernel_ms"], "bench_ms_per_step": line["ms_per_step"],
+                             "bench_stats_calls": int(row["Calls"]), "bench_stats_kernel": re.sub(r"\(anonymous namespace\)::|crd::|void ", "", row["Name"]).split("(")[0], "bench_kernel_ms_events": line["roofline"]["kernel_ms"], "bench_ms_per_step": line["ms_per_step"],
                              "bench_frac": line["roofline"]["frac"], "bench_frac_wall": line["roofline"]["frac_wall"], "bench_value": line["value"],
                              "bench_command": "rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 200 --warmup 20 --no-cpu-baseline --staged-steps 0 --launch-plan %s %s"
                                               % (",".join(str(v) for v in plan), " ".join(extra)),
