@@ -59,7 +59,7 @@ int ensure_staging(crd_ctx *c, size_t bytes)
 
 // One field plane.  Planes are whole multiples of 64 KiB (a row of 8192 doubles) and of 512 KiB at the BASELINE sizes, so with
 // back-to-back allocations element (j, i) of every plane a step touches -- two read, two written -- sits at the same offset
-// modulo any power-of-two interleave of the memory channels.  plane_skew (CRD_PLANE_SKEW, bytes) staggers the planes inside
+// modulo any power-of-two interleave of the memory channels.  plane_skew (bytes) staggers the planes inside
 // their allocations, plane number x skew, to take that alignment away.
 int alloc_plane(crd_ctx *c, int k, int f)
 {

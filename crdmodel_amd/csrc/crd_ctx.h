@@ -161,7 +161,7 @@ struct crd_ctx {
 	// rows were last exchanged, 0 = just exchanged), or -1 when the ghost rows cannot be trusted (new state, another stepper,
 	// an error): crd_step_rk4 then starts with an exchange, otherwise it carries on where the previous call stopped.
 	// Halo slack: sweeps of owned-only rows the compute stream launches after an exchange before it waits for the halo -- 1: the
-	// cycle's first step is split (rounds 1-2); 2: the first two are, for a third sweep of cover (crd_set_halo_slack, CRD_HALO_SLACK).
+	// cycle's first step is split (rounds 1-2); 2: the first two are, for a third sweep of cover (crd_set_halo_slack).
 	int halo_slack = 1;
 	int exchange_every = crd::kDefaultExchangeEvery;  // E: fused steps per deep-halo exchange (crd_set_exchange_period), the same on every slab of a run
 	int group_threads = 0;  // lead context of a LOCAL group: issuing threads of crd_group_step_rk4 (0 = one per device)
