@@ -169,6 +169,7 @@ struct crd_ctx {
 	double deferred_t = 0.0;      // that launch's time
 	int deferred_nsub = 1;        // ... and how many steps it takes (1, or 2 under a two-steps-per-launch plan)
 	int cycle_pos = -1;
+	int xchg_plane = 0;    // the state plane the exchange in progress sends this context's rows from (LOCAL neighbours pull from it)
 	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
 	int cycle_start = -1;  // the decision for the call in progress, taken for ALL slabs of the run before any thread issues (run_steps)
 	// RCCL runs: the ranks AGREE on the cycle position at the start of every stepping call (one 2-value ncclAllReduce(min) of

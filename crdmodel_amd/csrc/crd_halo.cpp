@@ -80,11 +80,13 @@ int exchange_local_pull(crd_ctx *c, int plane_index, int depth, bool with_v)
 	crd_ctx *prev = c->group[(size_t)((c->slab + c->n_slabs - 1) % c->n_slabs)];
 	crd_ctx *next = c->group[(size_t)((c->slab + 1) % c->n_slabs)];
 	const size_t bytes = (size_t)depth * (size_t)c->nx * c->real_size;
+	// (a neighbour's state need not sit in the plane of the same index: slabs whose launch plans pair steps differently have made
+	// different numbers of launches since the last exchange -- every context says where its rows are, xchg_plane)
 	for (int f = 0; f < (with_v ? 2 : 1); f++) {
 		void *mine = c->plane[plane_index][f];
-		HIP_TRY(c, hipMemcpyPeerAsync(c->row_ptr(mine, -depth), c->device, prev->row_ptr(prev->plane[plane_index][f], prev->nyl - depth), prev->device,
+		HIP_TRY(c, hipMemcpyPeerAsync(c->row_ptr(mine, -depth), c->device, prev->row_ptr(prev->plane[prev->xchg_plane][f], prev->nyl - depth), prev->device,
 		                              bytes, c->comm));
-		HIP_TRY(c, hipMemcpyPeerAsync(c->row_ptr(mine, c->nyl), c->device, next->row_ptr(next->plane[plane_index][f], 0), next->device, bytes, c->comm));
+		HIP_TRY(c, hipMemcpyPeerAsync(c->row_ptr(mine, c->nyl), c->device, next->row_ptr(next->plane[next->xchg_plane][f], 0), next->device, bytes, c->comm));
 	}
 	return CRD_OK;
 }
@@ -98,6 +100,7 @@ int exchange_stage_input(crd_ctx *const *cs, int n, int plane_index, int depth, 
 	// Several issuing threads (one per device of a LOCAL group): every thread has enqueued the records of its contexts'
 	// edge events before any thread makes a stream wait for a neighbour's.
 	TraceRange range(depth > kStepHalo + 1 ? "crd_halo_exchange(deep)" : "crd_halo_exchange");
+	for (int k = 0; k < n; k++) cs[k]->xchg_plane = plane_index;  // (read by the neighbours' pulls, behind the rendezvous below)
 	GroupBarrier *bar = cs[0]->bar;
 	if (bar && !bar->wait()) return fail(cs[0], CRD_ESTATE, "another slab's issuing thread failed");
 	// comm streams wait for the producers of the edge rows

@@ -35,7 +35,7 @@ while time.time() - t_start < budget:
     n_slabs = int(rng.integers(2, 5))
     big = episode % 10 == 9
     nx = int(rng.integers(1024, 1600)) if big else int(rng.integers(24, 300))
-    ny = n_slabs * int(rng.integers(40, 120)) + int(rng.integers(0, n_slabs))  # every slab holds the 32 ghost rows of the deep-halo cycle
+    ny = n_slabs * int(rng.integers(70, 160)) + int(rng.integers(0, n_slabs))  # every slab holds the ghost rows of the longest deep-halo cycle (64)
     precision = "f32" if rng.integers(4) == 0 else "f64"
     beta = 1.25 if model == "fhn" else 0.4
     t_b = float(rng.uniform(0.0, 0.02))
@@ -76,7 +76,24 @@ while time.time() - t_start < budget:
     upload_all(y)
     try:
         for _ in range(int(rng.integers(10, 40))):
-            op = int(rng.integers(10))
+            op = int(rng.integers(12))
+            if op >= 10:
+                # round 4: another exchange period (the same on every slab of a run), or a pinned launch plan -- the single slab, every slab
+                # of the group and the ring each draw their own from the tuner's candidates (two steps per launch included): the bits do
+                # not depend on the plan
+                if op == 10:
+                    e = int(rng.integers(3, 17))
+                    log.append("exchange period %d" % e)
+                    group.set_exchange_period(e)
+                    ring.set_exchange_period(e)
+                else:
+                    cands = crd.launch_plan_candidates()
+                    picks = [cands[int(rng.integers(len(cands)))] for _ in range(2 + n_slabs)]
+                    log.append("pinned plans (single, ring, slabs): %r" % (picks,))
+                    for ctx, pick in zip([single, ring] + list(group.slabs), picks):
+                        ctx.set_launch_plan(*pick)
+                n_ops += 1
+                continue
             if op == 9 and precision == "f32":
                 op = 0  # (the error-controlled integrators run at rtol 1e-5: fp64 only here)
             if op <= 4:
