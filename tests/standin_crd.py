@@ -94,7 +94,8 @@ class Slab:
         self.calls.append(("pin", plan))
 
     def launch_plan(self):
-        return {"autotune": 1, "tuned": 1, "one_round": 0, "xcd_mapping": 2, "rows": self.nyl, "columns_per_lane": 1, "nontemporal_stores": 0, "ms_default": 0.06, "ms_chosen": 0.058}
+        return {"autotune": 1, "tuned": 1, "one_round": 0, "xcd_mapping": 2, "rows": self.nyl, "columns_per_lane": 1, "nontemporal_stores": 0, "steps_per_launch": int(os.environ.get("STANDIN_STEPS_PER_LAUNCH", "1")),
+                "ms_default": 0.06, "ms_chosen": 0.058}
 
     def step_rk4(self, t0, dt, nsteps, sync=True):
         self.steps += nsteps

@@ -291,10 +291,14 @@ def test_bench_falls_back_to_the_local_transport_and_runs_it_on_request():
     non-zero at set-up), the LOCAL leg -- one process, all slabs, crd_group_step_rk4 -- still delivers a line, which says so; and
     --transport local asks for that leg directly.  --gpus 1 never launches anything."""
     common = ["--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--crd-module", "tests.standin_crd", "--preheat-ms", "0"]
-    r = _run_bench(["--gpus", "2", "--size", "64", "--transport", "local"] + common)
+    r = _run_bench(["--gpus", "2", "--size", "64", "--transport", "local"] + common, extra_env={"STANDIN_STEPS_PER_LAUNCH": "2"})
     assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["n_gpus"] == 2 and d["config"]["halo"]["transport"] == "local" and "launcher" not in d["config"] and len(d["per_rank"]) == 2
+    # a plan with two steps per launch: the launch's compulsory bytes are moved once per TWO steps, and the line says so
+    rf = d["roofline"]
+    assert rf["plan_key"].endswith("/steps2") and rf["steps_per_launch"] == 2 and rf["one_step_per_launch_equivalent"]["frac"] == pytest.approx(2 * rf["frac"])
+    assert rf["frac_wall"] == pytest.approx(4 * 8 * 64 * 64 / 2 / (d["ms_per_step"] * 1e-3) / 1e9 / 2 / 8000.0, rel=1e-9)
     # the ring's leg fails on every rank (exchange period out of range -> the stand-in's assertion), auto falls back
     r = _run_bench(["--gpus", "2", "--size", "64", "--exchange-period", "2"] + common)
     assert r.returncode != 0  # ... unless the local leg fails for the same reason: it does (same bad period), and the status says so
