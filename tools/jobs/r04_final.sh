@@ -31,5 +31,7 @@ b selfring_8192 --force-rccl --steps 200 --warmup 20 --no-cpu-baseline --staged-
 b local_two_slabs_one_device --gpus 2 --transport local --devices 0,0 --steps 100 --warmup 10 --no-cpu-baseline
 NYS=1024 STEPS=400 ROUNDS=5 VARIANTS="self,rccl,rccl:e16,rccl:s2,rccl:e16s2" timeout -k 10 300 python3 tools/ring_overhead.py > $OUT/ring_overhead_8192x1024.txt 2>&1; grep median $OUT/ring_overhead_8192x1024.txt
 NX=16384 NYS=2048 PRECISION=f32 STEPS=200 ROUNDS=3 VARIANTS="self,rccl,rccl:e16" timeout -k 10 300 python3 tools/ring_overhead.py > $OUT/ring_overhead_16384x2048_f32.txt 2>&1; grep median $OUT/ring_overhead_16384x2048_f32.txt
+# rocprofv3 --kernel-trace --stats of the driver's own command (the tuner's candidates are in it: the pinned-plan rows are plan_stats/)
+( cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/stats_default && timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/stats_default -- python3 $R/bench.py --steps 20 --warmup 5 > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err; cp $(find /tmp/stats_default -name "*kernel_stats.csv" | head -1) $OUT/bench_default_kernel_stats.csv )
 bash tools/jobs/r04_sweep.sh "fhn f64 8192" "goldbeter f64 4096" "fhn f32 16384" > $OUT/sweep_job.log 2>&1 || tail -5 $OUT/sweep_job.log
 bash tools/jobs/r04_plan_stats.sh > $OUT/plan_stats_job.log 2>&1; tail -2 $OUT/plan_stats_job.log | cut -c1-200
