@@ -1,0 +1,1175 @@
+#pragma once
+// crd_fused_impl.h -- (included by crd_fused.hip, the fp64 instantiations, and crd_fused_f32.hip, the fp32 ones: two translation
+// units so that the two halves of the instantiation matrix compile side by side)
+// One classical RK4 step of the whole slab in ONE kernel launch: all four RHS evaluations and the
+// stage updates happen on chip, so a grid-point-step costs one read and one write of the state (32 B in fp64) instead
+// of the 256 B the four stage kernels of crd_kernels.hip move.  Same arithmetic per point as the staged stepper.
+//
+// Structure (no LDS, no MFMA; no data passes between wavefronts -- the one barrier per iteration only keeps the four
+// wavefronts of a block in step): every WAVEFRONT is an independent work item.  It owns a strip of 64
+// consecutive theta columns -- one column per lane, 56 valid outputs in the middle and a 4-column apron on each side
+// that is recomputed redundantly -- and marches along phi through a chunk of rows as a 4-deep software pipeline:
+//   iteration m:  take row p        (state y0, fetched four iterations earlier)
+//                 stage 1 on row p-1 (needs y0 rows p-2..p)          -> y1 row p-1, acc row p-1
+//                 stage 2 on row p-2 (needs y1 rows p-3..p-1)        -> y2 row p-2
+//                 stage 3 on row p-3 (needs y2 rows p-4..p-2)        -> y3 row p-3
+//                 stage 4 on row p-4 (needs y3 rows p-5..p-3)        -> new state row p-4, stored
+// The phi neighbours of a row are the lane's own registers from neighbouring iterations; the theta neighbours are the
+// adjacent lanes' registers, fetched with DPP wavefront shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1).  Each stage
+// invalidates one more apron column per side, hence 4 + 4 of 64; chunks start 4 rows early and end 4 rows late for the
+// same reason in phi (rows come from the slab's ghost rows, or wrap for a single slab).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <type_traits>
+#include <utility>
+
+#include "crd_device.h"
+#include "crd_tuning.h"
+
+namespace crd {
+
+namespace {
+
+using namespace dev;
+
+constexpr int kApron = 4;                    // RK4 stages = halo depth
+constexpr int kLanes = 64;
+constexpr int kValid = kLanes - 2 * kApron;  // 56 output columns per wavefront
+constexpr int kWavesPerBlock = 4;     // default; the launch may use 1 .. kMaxWavesPerBlock (tuning knob)
+constexpr int kMaxWavesPerBlock = 4;  // (8 strips per workgroup never measured faster than 4)
+// Rows in flight per wavefront (a divisor of the unroll factor, so slots stay static).  Tuning builds override per model.
+#ifndef CRD_PREFETCH_FHN
+#define CRD_PREFETCH_FHN 4
+#endif
+#ifndef CRD_PREFETCH_GB
+#define CRD_PREFETCH_GB 4
+#endif
+// Rows in flight per wavefront of the two-steps-per-launch pipeline: 2 (an iteration is twice the arithmetic, so two rows cover the
+// time four cover in the one-step pipeline) -- and the 8 / 16 registers less are what takes fp32 x 2 columns and fp64 x 1 column from
+// 176 to 168 VGPRs, i.e. from two to three wavefronts per SIMD: 8192^2 fp64 0.2880 -> 0.2669 ms per step, fp32 0.1442 -> 0.1361
+// (profiles/r04/two_step_tune.txt).
+#ifndef CRD_PREFETCH_TWO
+#define CRD_PREFETCH_TWO 2
+#endif
+#ifndef CRD_EMBED_SLOTS
+#define CRD_EMBED_SLOTS 6
+#endif
+#ifndef CRD_PREFETCH_EMBED
+#define CRD_PREFETCH_EMBED 3
+#endif
+
+// Value held by lane-1 / lane+1 of this wavefront (the edge lane gets 0: it is apron garbage by design).  `old` = 0 with
+// bound_ctrl lets the DPP move write its destination without a tied input, i.e. without a copy in front of it.
+__device__ __forceinline__ double from_lane_below(double x)
+{
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	lo = __builtin_amdgcn_update_dpp(0, lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, true);
+	hi = __builtin_amdgcn_update_dpp(0, hi, 0x138, 0xf, 0xf, true);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_lane_above(double x)
+{
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	lo = __builtin_amdgcn_update_dpp(0, lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+	hi = __builtin_amdgcn_update_dpp(0, hi, 0x130, 0xf, 0xf, true);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float from_lane_below(float x)
+{
+	const int v = __float_as_int(x);
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x138, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_lane_above(float x)
+{
+	const int v = __float_as_int(x);
+	return __int_as_float(__builtin_amdgcn_update_dpp(0, v, 0x130, 0xf, 0xf, true));
+}
+// Two columns per lane, (x, y) = columns (2 lane, 2 lane + 1): the western neighbours of the pair are (lane-1's y, own x), the
+// eastern ones (own y, lane+1's x) -- one DPP move per direction for two columns instead of one per column.
+template <typename V2>
+__device__ __forceinline__ V2 pair_from_below(V2 v)
+{
+	V2 r;
+	r.x = from_lane_below(v.y);
+	r.y = v.x;
+	return r;
+}
+template <typename V2>
+__device__ __forceinline__ V2 pair_from_above(V2 v)
+{
+	V2 r;
+	r.x = v.y;
+	r.y = from_lane_above(v.x);
+	return r;
+}
+__device__ __forceinline__ float2v from_lane_below(float2v v) { return pair_from_below(v); }
+__device__ __forceinline__ float2v from_lane_above(float2v v) { return pair_from_above(v); }
+__device__ __forceinline__ double2v from_lane_below(double2v v) { return pair_from_below(v); }
+__device__ __forceinline__ double2v from_lane_above(double2v v) { return pair_from_above(v); }
+
+// f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a compile-time unrolled loop.
+template <typename F, int... Is>
+__device__ __forceinline__ void for_sequence(F &&f, std::integer_sequence<int, Is...>)
+{
+	(f(std::integral_constant<int, Is>{}), ...);
+}
+
+// row base (uniform) + this lane's byte offset
+template <typename T>
+__device__ __forceinline__ T *at_lane(T *row, unsigned byte_offset)
+{
+	using Bytes = std::conditional_t<std::is_const<T>::value, const char, char>;
+	// (the empty asm keeps the compiler from hoisting `constant pointer + lane offset` out of the row loop as a 64-bit vector
+	// base, which would cost a 64-bit vector add per access to put the row offset back in)
+	asm volatile("" : "+v"(byte_offset));
+	return reinterpret_cast<T *>(reinterpret_cast<Bytes *>(row) + byte_offset);
+}
+
+// ... the same address as a pointer to the lane's value (one Real, or two adjacent ones: an 8- or 16-byte access)
+template <typename V, typename T>
+__device__ __forceinline__ auto at_lane_as(T *row, unsigned byte_offset)
+{
+	using P = std::conditional_t<std::is_const<T>::value, const V, V>;
+	return reinterpret_cast<P *>(at_lane(row, byte_offset));
+}
+
+// a lane's value(s) added up in double
+__device__ __forceinline__ double lane_total(double x) { return x; }
+__device__ __forceinline__ double lane_total(float x) { return (double)x; }
+template <typename V2>
+__device__ __forceinline__ double lane_total(V2 v)
+{
+	return (double)v.x + (double)v.y;
+}
+
+// A value known to be identical in every lane, moved to scalar registers.
+__device__ __forceinline__ double uniform(double x)
+{
+	return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(x)), __builtin_amdgcn_readfirstlane(__double2loint(x)));
+}
+__device__ __forceinline__ float uniform(float x) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(x))); }
+
+// (non-temporal row loads measured 19 % slower, fp64 and fp32 alike: the apron rows and columns two items share come from cache)
+#define CRD_ROW_LOAD(p) (*(p))
+// The new state is written once and not read again by this launch.  NT = true gives its stores the non-temporal hint
+// (`global_store ... nt`): the lines do not stay in L2 at the expense of the apron rows and columns neighbouring items share --
+// a launch-plan choice (FusedPlan::nt), measured like the others: -6.5 % on 8192^2 fp64 under the plain mapping, -8 % at 4096^2,
+// +1 % on some two-column plans (profiles/r03/nt_stores.txt).
+template <bool NT, typename T>
+__device__ __forceinline__ void row_store(T *p, T v)
+{
+	if constexpr (NT) __builtin_nontemporal_store(v, p);
+	else *p = v;
+}
+
+template <typename Real>
+struct FusedArgs {
+	const Real *in_u, *in_v;  // y0, pointers to local row 0 (ghost rows at negative offsets)
+	Real *out_u, *out_v;      // new state, local row 0
+	Real h2, h3, h6, h1;      // dt/2, dt/3, dt/6, dt
+	int absorb[5];            // t_stage < tBoundary for the four stages (+ the embedded pair's fifth)
+	int absorb2[4];           // two steps per launch: the second step's stages
+	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
+	// Rows this launch produces: one or two ranges, cut into work items ("chunks") of `chunk` rows; chunk ids run through the
+	// ranges in order (range 1 starts at id `first2`).  One range: an ordinary sweep.  Two: the rows of a step that read ghost
+	// rows, below and above the slab, or the two edge bands of a cycle's last step.
+	int r_begin[2], r_end[2], chunk, first2;
+	int nstrips, nitems, nblocks, remap;
+	int xs_lanes;             // remap 2: phi-lanes of chunk sequences per strip block and XCD
+	int nchunks;              // chunks of both ranges
+	int sw;                   // wavefronts per block = adjacent strips a block covers
+	double *err_partials;     // EMBED: one weighted square sum per work item
+	Real rtol, atol;          // EMBED: error weights 1 / (rtol |y_n| + atol)
+	int err_lo, err_hi;       // EMBED: rows whose error counts (a multi-slab attempt also produces ghost-region rows: the owner counts those)
+};
+
+// EMBED adds a fifth pipeline stage and with it a local error estimate whose weighted square sum
+//   sum_i (err_i / (rtol |y_n,i| + atol))^2
+// over this work item's outputs is written to err_partials[item] (ARKode's WRMS norm, src/FHNmodel_torus.cpp:365, is
+// sqrt(sum / N)).  The propagated solution is classical RK4 either way.  The pipeline is then five rows / columns deep
+// (apron 5, 54 valid lanes) and uses 6 register slots per array, the loop being unrolled 6 times.
+//   EMBED = 1  the RK4(3) pair of rounds 1-2: k5 = f(t + dt, y_new), yhat = y + dt (k1/6 + k2/3 + k3/3 + k5/6), err = dt (k4 - k5)/6.
+//   EMBED = 2  ARKode's default fourth-order explicit table, Zonneveld 5(3)4 (what the reference integrates with,
+//              src/FHNmodel_torus.cpp:356-372; table and order conditions in oracle/arkode_erk.py): the fifth stage is
+//              k5 = f(t + 3/4 dt, y + dt (5/32 k1 + 7/32 k2 + 13/32 k3 - 1/32 k4)) and
+//              err = y_new - yhat = dt (2/3 k1 - 2 k2 - 2 k3 - 2 k4 + 16/3 k5).
+//              No accumulators in this variant: when stage 4 of a row runs, the row's stage values y1 = y + dt/2 k1,
+//              y2 = y + dt/2 k2, y3 = y + dt k3 are still in their register slots (six rows deep), so with
+//              d_i = y_i - y the three combinations the row needs come out of d1, d2, d3 and dt k4 there and then,
+//                y_new = y + (d1 + 2 d2 + d3)/3 + dt k4/6,   z5 = y + 5/16 d1 + 7/16 d2 + 13/32 d3 - dt k4/32,
+//                e4 = 4/3 d1 - 4 d2 - 2 d3 - 2 dt k4        (err = e4 + 16/3 dt k5 one iteration later);
+//              the subtractions are exact (y_i is within a factor 2 of y wherever it matters), so what this costs against running
+//              sums is a rounding of y_i itself, 1e-16 |y| in quantities that are compared with rtol |y| + atol.
+// COLS = 2: two adjacent grid columns per lane -- a wavefront's strip is 128 columns, 120 valid (the apron is two whole lanes a
+// side), rows are read and written with one 8-byte (fp32) or 16-byte (fp64) access per lane, a stage needs ONE DPP move per
+// direction for two columns, and the fp32 arithmetic is the packed instructions (v_pk_fma_f32 ...).  Needs an even nx (the
+// pair must not straddle the periodic seam); results are the one-column kernel's bit for bit.
+// NT = true: the new state is stored with the non-temporal hint (row_store above).
+// One work item: strip `strip` (a wavefront's columns) of chunk `chunk` (its rows).  ABSORB as a template argument of the ITEM: a
+// launch some stage of which has t < tBoundary runs the selects only in the items whose rows (aprons included) contain a global
+// phi boundary row -- two chunks per boundary of a launch; every other item runs the body without them (the kernel below decides
+// per chunk, uniformly for the block).  With the selects in every item the absorbing-rows run cost 5.4 % at 8192^2 (round 3).
+template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT>
+__device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk)
+{
+	static_assert(COLS == 1 || (COLS == 2 && EMBED == 0), "the embedded pairs run one column per lane");
+	using V = typename LaneValue<Real, COLS>::type;
+	constexpr bool ZONN = EMBED == 2;
+	constexpr int APRON = EMBED != 0 ? kApron + 1 : kApron;
+	static_assert(APRON % COLS == 0, "the apron is whole lanes");
+	constexpr int VALID = COLS * kLanes - 2 * APRON;
+	// Register slots per pipeline array = unroll factor: the rows alive at once (4, or 6 with the fifth stage) -- even, because
+	// the two-deep arrays below are addressed with the slot's parity.
+	constexpr int M = EMBED != 0 ? CRD_EMBED_SLOTS : 4;
+	static_assert(M % 2 == 0 && M >= (EMBED != 0 ? 6 : 4) && (EMBED != 2 || M % 3 == 0), "slot count");
+	constexpr int kPrefetch = EMBED != 0 ? ((MODEL == CRD_MODEL_GOLDBETER && sizeof(Real) == 8) ? 2 : CRD_PREFETCH_EMBED) : (MODEL == CRD_MODEL_GOLDBETER) ? CRD_PREFETCH_GB : CRD_PREFETCH_FHN;
+	static_assert(M % kPrefetch == 0, "prefetch slots are addressed with the unrolled iteration index");
+	const int lane = threadIdx.x & (kLanes - 1);
+	const int item = chunk * a.nstrips + strip;
+	const int nx = s.nx;
+
+	int x = strip * VALID - APRON + COLS * lane;  // this lane's (first) column, wrapped periodically (nx may be smaller than a strip)
+	x %= nx;
+	if (x < 0) x += nx;
+	// lane offsets in bytes, unsigned 32-bit: with a scalar row base the accesses take the `global_load v, v_off, s[base]` form and
+	// no 64-bit vector add is spent per access
+	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real), ob = (unsigned)(strip * VALID + (COLS * lane - APRON)) * (unsigned)sizeof(Real);
+	const int out_col = strip * VALID + (COLS * lane - APRON);
+	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;  // (two columns: nx is even, so is out_col)
+
+	const int range = chunk >= a.first2 ? 1 : 0;  // (an unused second range starts at nchunks)
+	const int range_end = a.r_end[range];
+	const int j0 = a.r_begin[range] + (chunk - (range ? a.first2 : 0)) * a.chunk;
+	const int j1 = (j0 + a.chunk < range_end) ? j0 + a.chunk : range_end;
+	const int jbase = j0 - APRON;
+	const int niter = (j1 - j0) + 2 * APRON;
+	const int jlast = j1 + APRON - 1;  // last row the pipeline consumes
+
+	const V cA = *reinterpret_cast<const V *>(s.cA + x), cP = *reinterpret_cast<const V *>(s.cP + x);
+	const Real cX = s.cX, ka4 = s.ka4;
+	const V h1 = (V)a.h1, h2 = (V)a.h2, h3 = (V)a.h3, h6 = (V)a.h6;
+	// b(j) is read-only for the whole launch and its index is uniform: through the constant address space the reads become
+	// scalar-cache loads into SGPRs (s_load_dwordx2), no vector registers and no vector-memory instruction
+	const __attribute__((address_space(4))) Real *const brow = (const __attribute__((address_space(4))) Real *)(s.brow);
+
+	// Row base pointers are scalar; a single slab wraps rows outside [0, nyl).  Branch-free: this runs once per pipeline
+	// iteration in every wavefront's instruction stream (scalar work is not free: ~40 of the ~140 instructions of an iteration
+	// were scalar before the row bookkeeping was pared down).
+	const int wrap_nyl = s.wrap ? s.nyl : 0;
+	auto row_base = [&](int j) -> ptrdiff_t {
+		j += wrap_nyl & (j >> 31);
+		j -= (j >= s.nyl) ? wrap_nyl : 0;
+		return (ptrdiff_t)j * nx;
+	};
+	// Global phi boundary rows (src/FHNmodel_torus.cpp:643-653), also when they are recomputed as another slab's ghost rows.
+	auto boundary_row = [&](int j) -> bool {
+		int gj = a.js + j;
+		if (gj < 0) gj += a.ny;
+		else if (gj >= a.ny) gj -= a.ny;
+		return gj == 0 || gj == a.ny - 1;
+	};
+
+	// Pipeline registers.  Row jbase+m of an array lives in slot m mod M (m & 1 for the two-deep v arrays), so with the
+	// loop unrolled M times every access has a compile-time slot and no value is ever moved between registers.
+	// (Zonneveld variant: the local field's stage values stay until the row's stage 4 has used them -- y1 four rows, y2 three)
+	constexpr int NV1 = ZONN ? M : 2, NV2 = ZONN ? 3 : 2;
+	V u0[M], v0[M], U1[M], U2[M], U3[M], V1[NV1], V2[NV2], V3[2], aU[M], aV[M];
+	// (Keeping aU / aV in LDS instead -- 90 VGPRs, five wavefronts per SIMD -- measured 3-5 % SLOWER on every grid: the twelve LDS
+	// accesses per iteration cost more than the fifth wavefront brings.)
+#define ACC_U(S) aU[S]
+#define ACC_V(S) aV[S]
+	V U4[M], V4[2], K4U[2], K4V[2];  // EMBED 1: y_new window and k4 of the last two rows; EMBED 2: z5 window (three rows deep) and e4
+	const V zero_v = splat<V>(0.0);
+	V err2 = zero_v;
+#pragma unroll
+	for (int k = 0; k < M; k++) u0[k] = v0[k] = U1[k] = U2[k] = U3[k] = aU[k] = aV[k] = U4[k] = zero_v;
+#pragma unroll
+	for (int k = 0; k < NV1; k++) V1[k] = zero_v;
+#pragma unroll
+	for (int k = 0; k < NV2; k++) V2[k] = zero_v;
+	V3[0] = V3[1] = V4[0] = V4[1] = K4U[0] = K4U[1] = K4V[0] = K4V[1] = zero_v;
+
+	// Rows are fetched kPrefetch iterations before they enter the pipeline: with ~16 wavefronts per CU one row in flight
+	// per wavefront is far too little to cover HBM latency (Little's law), four rows (8 loads, 4 KiB per wavefront) is enough.
+	// The per-row reaction parameter b(j) rides along: a plain `s.brow[c]` at the point of use is a VECTOR load whose
+	// full latency the stage then waits for (four exposed L2 round trips per iteration, 60 % of the wave's lifetime when
+	// measured); fetched with the row and moved to scalar registers on arrival it costs nothing.
+	V pu[kPrefetch], pv[kPrefetch];
+	Real pb[kPrefetch], bq[M];
+#pragma unroll
+	for (int k = 0; k < kPrefetch; k++) {
+		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
+		const ptrdiff_t rb = row_base(jr);
+		pu[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
+		pv[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
+		pb[k] = brow[jr];
+	}
+#pragma unroll
+	for (int k = 0; k < M; k++) bq[k] = (Real)0;
+	// running scalars of the row loop: the row the next prefetch takes (the tail re-reads the last valid row instead of running
+	// past the plane) and the output rows of stage 4 (row jbase + m - 4 at iteration m)
+	int jn = (jbase + kPrefetch < jlast) ? jbase + kPrefetch : jlast;
+	Real *out_row_u = a.out_u + (ptrdiff_t)(jbase - 4) * nx, *out_row_v = a.out_v + (ptrdiff_t)(jbase - 4) * nx;
+
+	// One pipeline iteration at m == K (mod M).  GUARDED: the first iterations of a chunk, where stage k's inputs exist only
+	// from iteration 2k on.
+	auto iteration = [&](int m, auto kk, auto guarded) {
+		constexpr int K = decltype(kk)::value;
+		constexpr bool GUARDED = decltype(guarded)::value;
+#ifndef CRD_NO_LOCKSTEP  // (an experiment switch: -DCRD_NO_LOCKSTEP lets a block's wavefronts drift)
+		__builtin_amdgcn_s_barrier();  // lockstep; uniform over the block: its wavefronts share the chunk, hence niter
+#endif
+		// slots of rows p, p-1, ... p-6 (with M = 4, row p-4 shares its slot with row p)
+		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M;
+		constexpr int S5 = (K + 2 * M - 5) % M, S6 = (K + 2 * M - 6) % M;
+		// slots of the local field's stage values (two deep; in the Zonneveld variant as deep as they have to live) and of the z5 window
+		constexpr int A1 = ZONN ? S1 : (S1 & 1), A2 = ZONN ? S2 : (S2 & 1), A4 = ZONN ? S4 : (S4 & 1);              // y1 rows p-1, p-2, p-4
+		constexpr int B2 = ZONN ? S2 % 3 : (S2 & 1), B3 = ZONN ? S3 % 3 : (S3 & 1), B4 = ZONN ? S4 % 3 : (S4 & 1);  // y2 rows p-2, p-3, p-4
+		constexpr int Z4 = ZONN ? S4 % 3 : S4, Z5 = ZONN ? S5 % 3 : S5, Z6 = ZONN ? S6 % 3 : S6;                    // z5 / y_new rows p-4, p-5, p-6
+		constexpr int P = K % kPrefetch;
+		const int p = jbase + m;
+		const Real b4 = bq[S4];  // b of row p-4 (stage 4), read before row p takes over the slot when M = 4
+		u0[S0] = pu[P];
+		v0[S0] = pv[P];
+		bq[S0] = uniform(pb[P]);
+		{
+			const ptrdiff_t rb = row_base(jn);
+			pu[P] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
+			pv[P] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
+			pb[P] = brow[jn];
+			jn = (jn < jlast) ? jn + 1 : jlast;
+		}
+		V du, dv;
+		// ---- stage 1, centre row p-1: y0 rows p-2, p-1, p -----------------------------------------------------
+		if (!GUARDED || m >= 2) {
+			const int c = p - 1;
+			rhs_point<V, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
+			                       ABSORB && a.absorb[0] && boundary_row(c), du, dv);
+			U1[S1] = fmadd(h2, du, u0[S1]);
+			V1[A1] = fmadd(h2, dv, v0[S1]);
+			if (!ZONN) {
+				ACC_U(S1) = fmadd(h6, du, u0[S1]);
+				ACC_V(S1) = fmadd(h6, dv, v0[S1]);
+			}
+		}
+		// ---- stage 2, centre row p-2: y1 rows p-3, p-2, p-1 ---------------------------------------------------
+		if (!GUARDED || m >= 4) {
+			const int c = p - 2;
+			rhs_point<V, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[A2], cA, cX, cP, bq[S2], ka4,
+			                       ABSORB && a.absorb[1] && boundary_row(c), du, dv);
+			U2[S2] = fmadd(h2, du, u0[S2]);
+			V2[B2] = fmadd(h2, dv, v0[S2]);
+			if (!ZONN) {
+				ACC_U(S2) = fmadd(h3, du, ACC_U(S2));
+				ACC_V(S2) = fmadd(h3, dv, ACC_V(S2));
+			}
+		}
+		// ---- stage 3, centre row p-3: y2 rows p-4, p-3, p-2 ---------------------------------------------------
+		if (!GUARDED || m >= 6) {
+			const int c = p - 3;
+			rhs_point<V, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[B3], cA, cX, cP, bq[S3], ka4,
+			                       ABSORB && a.absorb[2] && boundary_row(c), du, dv);
+			U3[S3] = fmadd(h1, du, u0[S3]);
+			V3[S3 & 1] = fmadd(h1, dv, v0[S3]);
+			if (!ZONN) {
+				ACC_U(S3) = fmadd(h3, du, ACC_U(S3));
+				ACC_V(S3) = fmadd(h3, dv, ACC_V(S3));
+			}
+		}
+		// ---- stage 4, centre row p-4: y3 rows p-5, p-4, p-3 -> the new state ----------------------------------
+		if (!GUARDED || m >= 8) {
+			const int c = p - 4;
+			rhs_point<V, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
+			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);
+			V nu, nv;
+			if (ZONN) {
+				// everything the row still needs, from its stage values (see the kernel's header comment)
+				const V yu = u0[S4], yv = v0[S4];
+				const V d1u = U1[S4] - yu, d2u = U2[S4] - yu, d3u = U3[S4] - yu, d1v = V1[A4] - yv, d2v = V2[B4] - yv, d3v = V3[S4 & 1] - yv;
+				nu = fmadd(splat<V>(1.0 / 3.0), fmadd(splat<V>(2.0), d2u, d1u + d3u), fmadd(h6, du, yu));
+				nv = fmadd(splat<V>(1.0 / 3.0), fmadd(splat<V>(2.0), d2v, d1v + d3v), fmadd(h6, dv, yv));
+				const V h32 = splat<V>(-1.0 / 32.0) * h1, h2m = splat<V>(-2.0) * h1;
+				U4[Z4] = fmadd(splat<V>(5.0 / 16.0), d1u, fmadd(splat<V>(7.0 / 16.0), d2u, fmadd(splat<V>(13.0 / 32.0), d3u, fmadd(h32, du, yu))));
+				V4[S4 & 1] = fmadd(splat<V>(5.0 / 16.0), d1v, fmadd(splat<V>(7.0 / 16.0), d2v, fmadd(splat<V>(13.0 / 32.0), d3v, fmadd(h32, dv, yv))));
+				K4U[S4 & 1] = fmadd(splat<V>(4.0 / 3.0), d1u, fmadd(splat<V>(-4.0), d2u, fmadd(splat<V>(-2.0), d3u, h2m * du)));
+				K4V[S4 & 1] = fmadd(splat<V>(4.0 / 3.0), d1v, fmadd(splat<V>(-4.0), d2v, fmadd(splat<V>(-2.0), d3v, h2m * dv)));
+			} else {
+				nu = fmadd(h6, du, ACC_U(S4));
+				nv = fmadd(h6, dv, ACC_V(S4));
+			}
+			// Without the fifth stage rows j0 <= c < j1 are exactly iterations 8 .. niter-1; with it (one more apron row each side)
+			// the first and the last iteration of the range fall outside.
+			if ((EMBED == 0 || (c >= j0 && c < j1)) && lane_stores) {
+				row_store<NT>(at_lane_as<V>(out_row_u, ob), nu);
+				row_store<NT>(at_lane_as<V>(out_row_v, ob), nv);
+			}
+			if (EMBED == 1) {
+				U4[S4] = nu;
+				V4[S4 & 1] = nv;
+				K4U[S4 & 1] = du;
+				K4V[S4 & 1] = dv;
+			}
+		}
+		// ---- stage 5 (EMBED), centre row p-5: y_new rows p-6, p-5, p-4 -> k5 and the error of row p-5 ----------
+		if (EMBED != 0 && (!GUARDED || m >= 10)) {
+			const int c = p - 5;
+			rhs_point<V, MODEL>(U4[Z5], from_lane_below(U4[Z5]), from_lane_above(U4[Z5]), U4[Z6], U4[Z4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
+			                       ABSORB && a.absorb[4] && boundary_row(c), du, dv);  // k5 at t + dt like k4 (EMBED 1) or at t + 3/4 dt (Zonneveld)
+			if (lane_stores && c >= a.err_lo && c < a.err_hi) {  // rows j0 .. j1-1 exactly (stage 5 starts at iteration 10, row j0, and the loop ends at row j1-1), owned rows only
+				const V au = __builtin_elementwise_abs(u0[S5]), av = __builtin_elementwise_abs(v0[S5]);
+				const V wu = fmadd((V)a.rtol, au, (V)a.atol), wv = fmadd((V)a.rtol, av, (V)a.atol);
+				V eu, ev;
+				if (ZONN) {
+					const V h163 = splat<V>(16.0 / 3.0) * h1;
+					eu = fmadd(h163, du, K4U[S5 & 1]) / wu;
+					ev = fmadd(h163, dv, K4V[S5 & 1]) / wv;
+				} else {
+					eu = h6 * (K4U[S5 & 1] - du) / wu;
+					ev = h6 * (K4V[S5 & 1] - dv) / wv;
+				}
+				err2 = fmadd(eu, eu, fmadd(ev, ev, err2));
+			}
+		}
+		out_row_u += nx;
+		out_row_v += nx;
+	};
+	using std::integral_constant;
+	// guarded prologue: up to the first multiple of M at or beyond 2 * APRON, so the steady-state loop starts at slot 0
+	constexpr int PRO = ((2 * APRON + M - 1) / M) * M;
+	for_sequence(
+	    [&](auto k) {
+		    constexpr int I = decltype(k)::value;
+		    if (I < niter) iteration(I, integral_constant<int, I % M>{}, std::true_type{});
+	    },
+	    std::make_integer_sequence<int, PRO>{});
+	int m = PRO;
+	for (; m + M - 1 < niter; m += M)  // steady state: M iterations per trip, every register slot a compile-time constant
+		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::false_type{}); }, std::make_integer_sequence<int, M>{});
+	for_sequence(
+	    [&](auto k) {
+		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::false_type{});
+	    },
+	    std::make_integer_sequence<int, M - 1>{});
+	if constexpr (EMBED != 0) {
+		// wavefront sum in a fixed order (butterfly over lane distances 32 .. 1), one partial per work item: the host-side
+		// reduction adds them in item order, so the norm is reproducible run to run
+		double sum = lane_total(err2);
+		for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+		if (lane == 0) a.err_partials[item] = sum;
+	}
+}
+
+// TWO classical RK4 steps of the item's rows in one pass over memory (STEPS = 2; round 4): the pipeline of fused_item twice over,
+// eight stages deep -- iteration m takes row p from memory, runs stages 1..4 of step n on rows p-1 .. p-4, hands the new row p-4
+// to a second, identical pipeline as ITS input row, which runs stages 1..4 of step n+1 on rows p-5 .. p-8 and stores row p-8.
+// The state crosses memory once per TWO steps: 8 B (fp32) / 16 B (fp64) per grid-point-step instead of 16 / 32.  What it costs:
+// the apron is 8 columns and 8 rows a side (112 valid columns of 128 with two columns per lane; 16 fill iterations per chunk,
+// hence 64-row chunks), twice the pipeline registers (two or three wavefronts per SIMD instead of four), and the first 16
+// iterations of a chunk run every stage on rows that are not all there yet -- harmless (nothing of them is stored, and the
+// arithmetic has no traps) and cheaper than sixteen specialised prologue iterations in the instruction cache.  The launch is bound
+// by vector issue, not by memory: the VALU is busy 94 % of it (profiles/r04/sq), so what counts is instructions per useful point.
+// (Tried for that, round 4, and dropped: the BLOCK as the strip -- one apron around four wavefronts' 256 lanes, 240 valid columns
+// instead of 4 x 48, the wavefronts' edge lanes taking their theta neighbours from the wavefront next door through LDS (written
+// one iteration ahead, double-buffered by the iteration's parity, the LDS value entering the DPP shift as its `old` operand so that
+// no instruction merges it).  Bit-identical, 20 % fewer vector instructions per point -- and slower: 0.305 ms per step at 8192^2
+// fp64 against 0.269 (173 VGPRs: two wavefronts per SIMD; held to three, spilling, 0.342), fp32 0.60 against 0.51;
+// profiles/r04/two_step_lds_exchange_ab.txt.)
+// Slot arithmetic: row r of either pipeline lives in slot r mod 4; the second pipeline's rows are the first one's shifted by 4,
+// i.e. the SAME slots -- the stage code is one lambda applied to two sets of arrays.  Per point the arithmetic is the sequence of
+// two single steps exactly (same fused multiply-adds, same constants), so the result is theirs bit for bit.
+template <typename Real, int MODEL, bool ABSORB, int COLS, bool NT>
+__device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk)
+{
+	using V = typename LaneValue<Real, COLS>::type;
+	constexpr int APRON = 2 * kApron;
+	static_assert(APRON % COLS == 0, "the apron is whole lanes");
+	constexpr int VALID = COLS * kLanes - 2 * APRON;
+	constexpr int M = 4;
+	constexpr int kPrefetch = CRD_PREFETCH_TWO;
+	static_assert(M % kPrefetch == 0, "prefetch slots are addressed with the unrolled iteration index");
+	const int lane = threadIdx.x & (kLanes - 1);
+	const int nx = s.nx;
+	int x = strip * VALID - APRON + COLS * lane;
+	x %= nx;
+	if (x < 0) x += nx;
+	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real), ob = (unsigned)(strip * VALID + (COLS * lane - APRON)) * (unsigned)sizeof(Real);
+	const int out_col = strip * VALID + (COLS * lane - APRON);
+	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;
+
+	const int range = chunk >= a.first2 ? 1 : 0;
+	const int range_end = a.r_end[range];
+	const int j0 = a.r_begin[range] + (chunk - (range ? a.first2 : 0)) * a.chunk;
+	const int j1 = (j0 + a.chunk < range_end) ? j0 + a.chunk : range_end;
+	const int jbase = j0 - APRON;
+	const int niter = (j1 - j0) + 2 * APRON;
+	const int jlast = j1 + APRON - 1;
+
+	const V cA = *reinterpret_cast<const V *>(s.cA + x), cP = *reinterpret_cast<const V *>(s.cP + x);
+	const Real cX = s.cX, ka4 = s.ka4;
+	const V h1 = (V)a.h1, h2 = (V)a.h2, h3 = (V)a.h3, h6 = (V)a.h6;
+	const __attribute__((address_space(4))) Real *const brow = (const __attribute__((address_space(4))) Real *)(s.brow);
+	const int wrap_nyl = s.wrap ? s.nyl : 0;
+	auto row_base = [&](int j) -> ptrdiff_t {
+		j += wrap_nyl & (j >> 31);
+		j -= (j >= s.nyl) ? wrap_nyl : 0;
+		return (ptrdiff_t)j * nx;
+	};
+	// Global phi boundary rows (src/FHNmodel_torus.cpp:643-653).  Rows ny - 1 and 0 are neighbours on the periodic grid: within the rows
+	// this item's pipeline touches (fewer than 2 ny of them) they are local rows jb, jb + 1 and possibly jb + ny, jb + ny + 1.  Two
+	// scalars and a bit mask of the eight stage flags instead of js, ny and eight flag words: the body with the selects must not need
+	// more registers than the one without (168 VGPRs = three wavefronts per SIMD), or the launch's kernel, which holds both, runs
+	// every item at two.
+	int jb = 0, amask = 0;
+	if (ABSORB) {
+		int g0 = (a.js + jbase) % a.ny;  // global row of the first row the pipeline takes
+		if (g0 < 0) g0 += a.ny;
+		jb = jbase + (a.ny - 1 - g0);
+#pragma unroll
+		for (int k = 0; k < 4; k++) amask |= (a.absorb[k] ? 1 << k : 0) | (a.absorb2[k] ? 16 << k : 0);
+		jb = __builtin_amdgcn_readfirstlane(jb);
+		amask = __builtin_amdgcn_readfirstlane(amask);
+	}
+	const int ny_rows = a.ny;
+	auto boundary_row = [&](int j) -> bool { return (unsigned)(j - jb) <= 1u || (unsigned)(j - jb - ny_rows) <= 1u; };
+
+	struct Pipe {
+		V u0[M], v0[M], U1[M], U2[M], U3[M], V1[2], V2[2], V3[2], aU[M], aV[M];
+		Real bq[M];
+	};
+	Pipe A, B;
+	const V zero_v = splat<V>(0.0);
+#pragma unroll
+	for (int k = 0; k < M; k++) {
+		A.u0[k] = A.v0[k] = A.U1[k] = A.U2[k] = A.U3[k] = A.aU[k] = A.aV[k] = zero_v;
+		B.u0[k] = B.v0[k] = B.U1[k] = B.U2[k] = B.U3[k] = B.aU[k] = B.aV[k] = zero_v;
+		A.bq[k] = B.bq[k] = (Real)0;
+	}
+	A.V1[0] = A.V1[1] = A.V2[0] = A.V2[1] = A.V3[0] = A.V3[1] = zero_v;
+	B.V1[0] = B.V1[1] = B.V2[0] = B.V2[1] = B.V3[0] = B.V3[1] = zero_v;
+
+	V pu[kPrefetch], pv[kPrefetch];
+	Real pb[kPrefetch];
+#pragma unroll
+	for (int k = 0; k < kPrefetch; k++) {
+		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
+		const ptrdiff_t rb = row_base(jr);
+		pu[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
+		pv[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
+		pb[k] = brow[jr];
+	}
+	int jn = (jbase + kPrefetch < jlast) ? jbase + kPrefetch : jlast;
+	Real *out_row_u = a.out_u + (ptrdiff_t)(jbase - 2 * kApron) * nx, *out_row_v = a.out_v + (ptrdiff_t)(jbase - 2 * kApron) * nx;
+
+	// Stages 1..4 of one step on the pipeline P whose newest row is `p` (slot S0): new state of row p - 4 in (nu, nv).
+	// flag_bit: where the step's four stage flags start in amask; b4: b(j) of row p - 4 (read by the caller before row p took over its slot).
+	auto stages = [&](Pipe &P, const int p, auto kk, const int flag_bit, const Real b4, V &nu, V &nv) {
+		constexpr int K = decltype(kk)::value;
+		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M, S5 = (K + 2 * M - 5) % M;
+		V du, dv;
+		rhs_point<V, MODEL>(P.u0[S1], from_lane_below(P.u0[S1]), from_lane_above(P.u0[S1]), P.u0[S2], P.u0[S0], P.v0[S1], cA, cX, cP, P.bq[S1], ka4,
+		                       ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), du, dv);
+		P.U1[S1] = fmadd(h2, du, P.u0[S1]);
+		P.V1[S1 & 1] = fmadd(h2, dv, P.v0[S1]);
+		P.aU[S1] = fmadd(h6, du, P.u0[S1]);
+		P.aV[S1] = fmadd(h6, dv, P.v0[S1]);
+		rhs_point<V, MODEL>(P.U1[S2], from_lane_below(P.U1[S2]), from_lane_above(P.U1[S2]), P.U1[S3], P.U1[S1], P.V1[S2 & 1], cA, cX, cP, P.bq[S2], ka4,
+		                       ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), du, dv);
+		P.U2[S2] = fmadd(h2, du, P.u0[S2]);
+		P.V2[S2 & 1] = fmadd(h2, dv, P.v0[S2]);
+		P.aU[S2] = fmadd(h3, du, P.aU[S2]);
+		P.aV[S2] = fmadd(h3, dv, P.aV[S2]);
+		rhs_point<V, MODEL>(P.U2[S3], from_lane_below(P.U2[S3]), from_lane_above(P.U2[S3]), P.U2[S4], P.U2[S2], P.V2[S3 & 1], cA, cX, cP, P.bq[S3], ka4,
+		                       ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), du, dv);
+		P.U3[S3] = fmadd(h1, du, P.u0[S3]);
+		P.V3[S3 & 1] = fmadd(h1, dv, P.v0[S3]);
+		P.aU[S3] = fmadd(h3, du, P.aU[S3]);
+		P.aV[S3] = fmadd(h3, dv, P.aV[S3]);
+		rhs_point<V, MODEL>(P.U3[S4], from_lane_below(P.U3[S4]), from_lane_above(P.U3[S4]), P.U3[S5], P.U3[S3], P.V3[S4 & 1], cA, cX, cP, b4, ka4,
+		                       ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), du, dv);
+		nu = fmadd(h6, du, P.aU[S4]);
+		nv = fmadd(h6, dv, P.aV[S4]);
+	};
+	auto iteration = [&](int m, auto kk) {
+		constexpr int K = decltype(kk)::value;
+		constexpr int S0 = K % M, S4 = (K + 2 * M - 4) % M, P0 = K % kPrefetch;
+#if !defined(CRD_NO_LOCKSTEP) && !defined(CRD_NO_LOCKSTEP_TWO)
+		__builtin_amdgcn_s_barrier();
+#endif
+		const int p = jbase + m;
+		const Real b4a = A.bq[S4], b4b = B.bq[S4];
+		A.u0[S0] = pu[P0];
+		A.v0[S0] = pv[P0];
+		A.bq[S0] = uniform(pb[P0]);
+		{
+			const ptrdiff_t rb = row_base(jn);
+			pu[P0] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
+			pv[P0] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
+			pb[P0] = brow[jn];
+			jn = (jn < jlast) ? jn + 1 : jlast;
+		}
+		V nu, nv;
+		stages(A, p, kk, 0, b4a, nu, nv);  // step n: the new row p - 4 ...
+		B.u0[S0] = nu;                            // ... is the second pipeline's newest row (same slot: rows shifted by 4)
+		B.v0[S0] = nv;
+		B.bq[S0] = b4a;
+		stages(B, p - kApron, kk, 4, b4b, nu, nv);  // step n + 1: the new row p - 8
+		if (m >= 4 * kApron && lane_stores) {  // rows j0 .. j1 - 1 exactly
+			row_store<NT>(at_lane_as<V>(out_row_u, ob), nu);
+			row_store<NT>(at_lane_as<V>(out_row_v, ob), nv);
+		}
+		out_row_u += nx;
+		out_row_v += nx;
+	};
+	int m = 0;
+	for (; m + M - 1 < niter; m += M)
+		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k); }, std::make_integer_sequence<int, M>{});
+	for_sequence(
+	    [&](auto k) {
+		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k);
+	    },
+	    std::make_integer_sequence<int, M - 1>{});
+}
+
+// ABSORB = false: no stage of the step has t < tBoundary (every launch after the switch-off time, every launch of a run with
+// tBoundary = 0) -- the absorbing-row selects are compiled out.  ABSORB = true: the items that can meet a global phi boundary row
+// (src/FHNmodel_torus.cpp:643-653) run the body with the selects, all others the body without (see fused_item).
+// EMBED, COLS, NT: see FusedArgs / fused_item above.
+// STEPS = 2: two steps per launch (fused_item_two_steps).
+template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false, int STEPS = 1>
+__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
+{
+	static_assert(STEPS == 1 || (STEPS == 2 && EMBED == 0), "two steps per launch: the plain step only");
+	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
+	// per-row table reads, the boundary-row tests) in scalar registers.
+	// Optional remap: blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of items.
+	// A block's wavefronts take adjacent strips of ONE chunk, blocks walk theta first.  The wavefronts of a block therefore
+	// run the same trip counts, and in lockstep (one barrier per pipeline iteration) their row reads reach the memory system
+	// together as one contiguous, overlapping run of a.sw x 448 B per row instead of drifting apart.
+	const int nsb = (a.nstrips + a.sw - 1) / a.sw;
+	int sblk, cblk;
+	{
+		const int b0 = (int)blockIdx.x;
+		const int blk = a.remap == 1 ? xcd_remap(b0, a.nblocks) : b0;
+		sblk = blk % nsb;
+		cblk = blk / nsb;
+		if (a.remap == 2) {
+			// Succession in phi: XCD x owns a contiguous run of chunks; its resident workgroups form `xs_lanes` lanes per strip
+			// block, and the workgroup that takes a finished one's place (ids are dispatched in order, 8 apart on one XCD) continues
+			// that lane with the NEXT chunk in phi -- whose first rows are the rows its predecessor has just read into this L2.
+			const int x = blk % kNumXcd, p = blk / kNumXcd, width = nsb * a.xs_lanes;
+			const int d = p / width, sl = p - d * width;
+			const int c0 = (int)((long)a.nchunks * x / kNumXcd), c1 = (int)((long)a.nchunks * (x + 1) / kNumXcd);
+			const int depth = (c1 - c0 + a.xs_lanes - 1) / a.xs_lanes, lane_id = sl / nsb;
+			sblk = sl - lane_id * nsb;
+			cblk = (d < depth && c0 + lane_id * depth + d < c1) ? c0 + lane_id * depth + d : a.nchunks;  // nchunks: nothing to do
+		}
+	}
+	const int strip = __builtin_amdgcn_readfirstlane(sblk * a.sw + (int)(threadIdx.x >> 6));
+	const int chunk = __builtin_amdgcn_readfirstlane(cblk);
+	if (strip >= a.nstrips || chunk >= a.nchunks) return;  // (a barrier waits for the surviving wavefronts of the workgroup only)
+	if constexpr (ABSORB) {
+		// Does any row this chunk's pipeline touches -- [j0 - APRON, j1 + APRON) -- map to global row 0 or ny - 1?  The two are
+		// neighbours on the periodic grid: the rows contain one of them exactly when [lo, hi + 1] contains a multiple of ny.
+		constexpr int APRON = STEPS * (EMBED != 0 ? kApron + 1 : kApron);
+		const int range = chunk >= a.first2 ? 1 : 0;
+		const int j0 = a.r_begin[range] + (chunk - (range ? a.first2 : 0)) * a.chunk;
+		const int j1 = (j0 + a.chunk < a.r_end[range]) ? j0 + a.chunk : a.r_end[range];
+		const int lo = a.js + j0 - APRON, hi1 = a.js + j1 + APRON;  // (lo > -ny and hi1 < 3 ny: a slab is at most the grid, ghost rows at most a slab)
+		const bool touches = (lo <= 0 && 0 <= hi1) || (lo <= a.ny && a.ny <= hi1) || (lo <= 2 * a.ny && 2 * a.ny <= hi1);
+		if constexpr (STEPS == 2) {
+			if (touches) fused_item_two_steps<Real, MODEL, true, COLS, NT>(s, a, strip, chunk);
+			else fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk);
+		} else {
+			if (touches) fused_item<Real, MODEL, true, EMBED, COLS, NT>(s, a, strip, chunk);
+			else fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
+		}
+	} else if constexpr (STEPS == 2) {
+		fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk);
+	} else {
+		fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
+	}
+}
+
+// Adds the per-item error sums in a fixed order (thread t takes items t, t+256, ...; then a fixed LDS tree), so the error
+// norm, and with it every accept / reject decision of the adaptive stepper, is reproducible from run to run.
+__global__ void __launch_bounds__(256) crd_sum_partials_kernel(const double *__restrict__ partials, int n, double *__restrict__ out)
+{
+	__shared__ double part[256];
+	double sum = 0.0;
+	for (int q = threadIdx.x; q < n; q += 256) sum += partials[q];
+	part[threadIdx.x] = sum;
+	__syncthreads();
+	for (int w = 128; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) part[threadIdx.x] += part[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *out = part[0];
+}
+
+// Rows per work item.  Every item pays 8 apron rows, which argues for long chunks; but the wavefronts of a launch run in
+// "rounds" of (resident wavefront slots) items, a partly filled last round idles most of the chip, unequal wavefront
+// speeds cost about half a round at the end whatever the count, and short chunks keep the rows two phi-neighbouring items
+// share in L2.  Measured on 8192^2 fp64 (147 strips, 4096 slots; 200-step medians, one process, tools/tune_fused.py):
+// chunk 32 0.434 ms, 24 0.451, 50 0.463, 60 0.477, 75 0.494, 128 0.51, 1024 0.62 -- many short items win.  So: 32 rows,
+// halved while the launch would not fill every slot once (an 8192 x 1024 slab, one rank's share of 8 GPUs, sweeps in
+// 58.4 us with 32-row chunks and 60.5 with 16; the edge-band launches of a multi-slab step end up with 8-row chunks).
+// `one_round` (a launch-plan choice, see FusedPlan): a launch that needs more than one round of resident blocks but would
+// fit into one with chunks of up to 96 rows gets those longer chunks -- no tail round on an almost idle chip.
+int device_cus()
+{
+	// compute units of a device of this node (the GPUs of a node are alike); initialised once, also when several issuing threads of a
+	// LOCAL group arrive together
+	static const int cus = [] {
+		int dev = 0;
+		hipDeviceProp_t prop;
+		const int n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+		(void)hipGetLastError();
+		return n;
+	}();
+	return cus;
+}
+
+template <typename Real, int MODEL, int COLS, int STEPS>
+int resident_wavefronts()
+{
+	// resident wavefronts of this kernel on a device of this node (initialised once, thread-safely: the issuing threads of a LOCAL group
+	// may arrive together)
+	static const int slots = [] {
+		int blocks_per_cu = 4;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&blocks_per_cu, crd_rk4_fused_step_kernel<Real, MODEL, false, 0, COLS, false, STEPS>, kLanes * kWavesPerBlock, 0) != hipSuccess ||
+		    blocks_per_cu < 1)
+			blocks_per_cu = 4;
+		(void)hipGetLastError();
+		return device_cus() * blocks_per_cu * kWavesPerBlock;
+	}();
+	return slots;
+}
+
+template <typename Real, int MODEL>
+int resident_wavefronts(int cols, int steps = 1)
+{
+	if constexpr (MODEL != kModelDiffusionOnly)  // (the diffusion-only variant has no two-step instantiation)
+		if (steps == 2) return cols == 2 ? resident_wavefronts<Real, MODEL, 2, 2>() : resident_wavefronts<Real, MODEL, 1, 2>();
+	return cols == 2 ? resident_wavefronts<Real, MODEL, 2, 1>() : resident_wavefronts<Real, MODEL, 1, 1>();
+}
+
+template <typename Real, int MODEL>
+int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols, int steps = 1)  // 0: 32 rows, 1: one round, 2: 64 rows (two steps per launch: twice that)
+{
+	bool one_round = chunk_mode == 1;
+	const int slots = resident_wavefronts<Real, MODEL>(cols, steps);
+	// Two steps per launch: 16 fill rows per chunk instead of 8, and a pipeline bound by issue, not by the memory system: 128-row
+	// chunks (8192^2 fp64: 48 rows 0.301 ms per step, 64 0.289, 96 0.278, 128 0.267, 192 0.276, 256 0.276; fp32 alike,
+	// profiles/r04/two_step_tune.txt); chunk mode 2 is the 64-row alternative there.
+	int chunk = steps == 2 ? (chunk_mode == 2 ? 64 : 128) : 32;
+	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
+	// Tiny launches: where even 8-row chunks make fewer blocks than half the CUs, 4-row chunks put twice as many CUs to work (256^2:
+	// 7.3 -> 6.4 us per step; the reference's 100 x 400 Goldbeter grid: 8.2 -> 6.5).  With more blocks than that the extra apron rows
+	// cost more than they bring (512^2: 8.9 -> 9.8 us, 400 x 1600: 11.1 -> 12.9; the edge bands of a ring share: no change).
+	if (chunk == 8 && (long)((nstrips + kWavesPerBlock - 1) / kWavesPerBlock) * ((rows + 7) / 8) < device_cus() / 2) chunk = 4;
+	if (const char *e = tuning::knob("CRD_FUSED_ONEROUND")) one_round = std::atoi(e) != 0;  // tuning knob
+	if (steps == 1 && chunk_mode == 2 && chunk == 32 && (long)nstrips * ((rows + 63) / 64) >= 2L * slots) chunk = 64;  // fewer apron rows recomputed: pays where fp64 issue binds (Goldbeter)
+	if (one_round && steps == 1) {
+		const long strip_blocks = (nstrips + kWavesPerBlock - 1) / kWavesPerBlock, fit = (slots / kWavesPerBlock) / strip_blocks;
+		const long need = fit >= 1 ? (rows + fit - 1) / fit : 0;
+		if (need > chunk && need <= 96) chunk = (int)need;
+	}
+	if (one_round && steps == 2) {
+		// Two steps per launch are bound by issue, and what a launch loses is its last, partly filled round of resident blocks: chunks
+		// such that the launch is just under a WHOLE NUMBER of rounds -- the fewest rounds whose chunks stay within 288 rows (longer
+		// ones have fewer fill rows per row; 8192^2 fp64: 128 rows = 3.6 rounds 0.2667 ms per step, 155 = 2.97 rounds 0.2617, 235 =
+		// 1.96 rounds 0.2618, but 161 = 2.86 rounds 0.2669 and 241 = 1.90 rounds 0.2697; 16384^2 fp32: 128 rows 0.4948, 274 rows 0.4830;
+		// a rank's share of 1024 rows: one round of 61 rows; profiles/r04/whole_rounds.txt).
+		const long strip_blocks = (nstrips + kWavesPerBlock - 1) / kWavesPerBlock, resident_blocks = slots / kWavesPerBlock;
+		for (long k = 1; k <= 8; k++) {
+			const long chunks = k * resident_blocks / strip_blocks;
+			if (chunks < 1) continue;
+			const long need = (rows + chunks - 1) / chunks;
+			if (need <= 288) {
+				if (need >= 16) chunk = (int)need;
+				break;
+			}
+		}
+	}
+	if (const char *e = tuning::knob("CRD_FUSED_CHUNK")) {  // tuning knob
+		const int v = std::atoi(e);
+		if (v >= 1) chunk = v;
+	}
+	return chunk < rows ? chunk : rows;
+}
+
+// Launch-plan candidates the autotuner times: (chunks stretched to one round?, block -> item mapping).  Workgroups are dealt
+// round-robin to the 8 XCDs, each with its own L2.  Mapping 0 walks the items theta-first in dispatch order: neighbouring
+// items land on different XCDs and every apron column and row is fetched from beyond L2 by both items that need it (PMC:
+// 39.5 B per point, reads 1.47 x the plane).  Mapping 1 gives each XCD one contiguous run of items, i.e. a contiguous band of
+// the slab: theta-neighbours share an L2 and the apron columns are fetched once (36.6 B per point, reads 1.29 x).  Mapping 2
+// adds succession in phi -- the workgroup that takes a finished one's place continues with the next chunk in phi, whose first
+// rows its predecessor has just pulled into that L2 (34.9 B per point, reads 1.18 x).  Which plan is fastest depends on the
+// grid shape AND on the device: on 8192^2 fp64 mapping 1 measured -6.3 %, -0.7 % and +1.7 % against mapping 0 on three
+// MI355X of the same pool, mapping 2 -4.4 % on a fourth; one-round chunks -10 % (4096 x 1024) to +2 % (16384 x 2048 fp32) --
+// hence measured at run time, on the device and the shape at hand.  Every candidate computes bit-identical results.
+// Third dimension (round 3): columns per lane.  Two columns per lane halve the DPP moves and the apron share of a strip (8 of 128
+// columns instead of 8 of 64) and, in fp32, use the packed arithmetic; they also halve the wavefronts in flight for the same
+// bytes.  Which wins is again a matter of the kernel (fp32 / Goldbeter are issue-bound, FHN fp64 is not) and of the device.
+// Fourth dimension (round 3, late): non-temporal stores of the new state (row_store).  They keep L2 for what items share; which
+// mapping is fastest changes with them (the plain mapping gains most), so they are timed in combination.
+struct PlanCandidate {
+	int one_round, remap, cols, nt;  // one_round: the chunk mode -- 0 = 32 rows, 1 = stretched to one round, 2 = 64 rows
+	int steps = 1;                   // RK4 steps per launch (2: fused_item_two_steps)
+};
+// (round 4: 64-row chunks also under mappings 1 / 2 and with two columns per lane -- where fp64 issue binds, Goldbeter, the recompute
+// factor of the apron rows is what is left to cut: (64 + 8) / 64 x 128 / 120 = 1.20 against (32 + 8) / 32 x 64 / 56 = 1.43)
+constexpr PlanCandidate kPlanCandidates[] = {
+    {0, 0, 1, 0}, {0, 1, 1, 0}, {0, 2, 1, 0}, {1, 0, 1, 0}, {1, 1, 1, 0}, {2, 0, 1, 0}, {2, 1, 1, 0}, {2, 2, 1, 0},
+    {0, 0, 2, 0}, {0, 1, 2, 0}, {0, 2, 2, 0}, {1, 0, 2, 0}, {1, 1, 2, 0}, {2, 0, 2, 0}, {2, 1, 2, 0}, {2, 2, 2, 0},
+    {0, 0, 1, 1}, {0, 1, 1, 1}, {0, 2, 1, 1}, {1, 0, 1, 1}, {1, 1, 1, 1}, {2, 0, 1, 1}, {2, 1, 1, 1}, {2, 2, 1, 1},
+    {0, 0, 2, 1}, {0, 1, 2, 1}, {0, 2, 2, 1}, {1, 0, 2, 1}, {1, 1, 2, 1}, {2, 0, 2, 1}, {2, 1, 2, 1}, {2, 2, 2, 1},
+    // fifth dimension (round 4): two steps per launch (128-row chunks, or 64), non-temporal stores
+    {0, 0, 1, 1, 2}, {0, 1, 1, 1, 2}, {0, 2, 1, 1, 2}, {1, 0, 1, 1, 2}, {1, 1, 1, 1, 2}, {2, 1, 1, 1, 2},
+    {0, 0, 2, 1, 2}, {0, 1, 2, 1, 2}, {0, 2, 2, 1, 2}, {1, 0, 2, 1, 2}, {1, 1, 2, 1, 2}, {2, 1, 2, 1, 2}};
+constexpr int kNumPlanCandidates = (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]);
+
+template <typename Real, int MODEL>
+hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, int js, int ny,
+                          hipStream_t st)
+{
+	clear_launch_status();
+	if (row_end <= row_begin) return hipSuccess;
+	if (row_end2 < row_begin2) row_end2 = row_begin2;
+	// Two steps per launch: plain steps only, and not the diffusion-only variant (no instantiation: that model is a plumbing case).
+	constexpr bool kCanTwoSteps = MODEL != kModelDiffusionOnly;
+	if (c.steps != 1 && (c.steps != 2 || c.embed || !kCanTwoSteps)) return hipErrorInvalidValue;
+	// rows may extend into the ghost region (deep-halo steps), but the pipeline reads kStepHalo rows per step beyond them
+	if (!d.wrap && (row_begin < -(kGhost - c.steps * kStepHalo) || row_end > d.nyl + (kGhost - c.steps * kStepHalo))) return hipErrorInvalidValue;
+	const Slab<Real> s = typed<Real>(d);
+	FusedArgs<Real> a;
+	a.in_u = row0<Real>(c.y0.u, d.nx);
+	a.in_v = row0<Real>(c.y0.v, d.nx);
+	a.out_u = row0<Real>(c.yout.u, d.nx);
+	a.out_v = row0<Real>(c.yout.v, d.nx);
+	a.h2 = (Real)(0.5 * c.dt);
+	a.h3 = (Real)(c.dt / 3.0);
+	a.h6 = (Real)(c.dt / 6.0);
+	a.h1 = (Real)c.dt;
+	for (int k = 0; k < 5; k++) a.absorb[k] = c.absorb[k];
+	for (int k = 0; k < 4; k++) a.absorb2[k] = c.absorb2[k];
+	a.js = js;
+	a.ny = ny;
+	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
+	// two columns per lane need an even nx (a pair must not straddle the periodic seam; rows then are 8- / 16-byte aligned too)
+	const bool cols2_ok = !c.embed && d.nx % 2 == 0;
+	// (where nothing has been measured: the packed arithmetic for fp32, one column for fp64 -- fused_default_columns)
+	int cols_default = (cols2_ok && sizeof(Real) == 4) ? 2 : 1;
+	if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols_default = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
+	// Four adjacent strips per block marching in lockstep: 0.417 ms on 8192^2 fp64 against 0.441 without the barriers and
+	// 0.4205 with one barrier per four iterations (tools/tune_fused.py, interleaved in one process; fp32 0.219 vs 0.232,
+	// Goldbeter -- instruction-bound -- unchanged); 2 or 8 strips per block lose half of the gain, 3 / 5 / 6 more.
+	int sw = kWavesPerBlock;
+	if (const char *e = tuning::knob("CRD_FUSED_STRIPS")) {
+		const int v = std::atoi(e);
+		if (v >= 1 && v <= kMaxWavesPerBlock) sw = v;
+	}
+	a.sw = sw;
+	a.err_partials = c.err_partials;
+	a.err_lo = d.wrap ? INT32_MIN : 0;
+	a.err_hi = d.wrap ? INT32_MAX : d.nyl;
+	a.rtol = (Real)c.rtol;
+	a.atol = (Real)c.atol;
+	// the reaction block of a diffusion-only run is skipped, absorbing rows included (src/GoldbeterModel_torus.cpp:668)
+	constexpr bool kCanAbsorb = MODEL != kModelDiffusionOnly;
+	const bool absorb1 = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3] || (c.embed && c.absorb[4]));
+	const bool absorb12 = absorb1 || (kCanAbsorb && (c.absorb2[0] || c.absorb2[1] || c.absorb2[2] || c.absorb2[3]));
+	const dim3 block(kLanes * sw);
+
+	int cols = cols_default, steps = 1;
+	bool nt = false;
+	// The launch's geometry in two layers: configure() fixes the plan's choices, layout() cuts the rows in R -- the caller's, or
+	// a part of them (fire() below) -- into items accordingly.
+	int R[4] = {row_begin, row_end, row_begin2, row_end2}, plan_mode = 0, plan_remap = 0, chunk_override = 0;
+	auto layout = [&]() {
+		const int rows_a = R[1] - R[0], rows_b = R[3] - R[2];
+		const int nsb = (a.nstrips + sw - 1) / sw;
+		a.chunk = chunk_override > 0 ? std::min(chunk_override, rows_a + rows_b) : fused_chunk_rows<Real, MODEL>(a.nstrips, rows_a + rows_b, plan_mode, cols, steps);
+		const int n1 = (rows_a + a.chunk - 1) / a.chunk, n2 = (rows_b + a.chunk - 1) / a.chunk;
+		a.nchunks = n1 + n2;
+		a.first2 = n2 > 0 ? n1 : a.nchunks;
+		a.r_begin[0] = R[0];
+		a.r_end[0] = R[1];
+		a.r_begin[1] = R[2];
+		a.r_end[1] = R[3];
+		a.nitems = a.nstrips * a.nchunks;
+		a.nblocks = nsb * a.nchunks;
+		a.remap = plan_remap;
+		if (const char *e = tuning::knob("CRD_FUSED_REMAP")) a.remap = std::atoi(e);
+		a.xs_lanes = 1;
+		if (a.remap == 2) {
+			const int per_xcd = resident_wavefronts<Real, MODEL>(cols, steps) / sw / kNumXcd;
+			if (rows_b > 0 || a.nchunks < 2 * kNumXcd || per_xcd < nsb) {
+				a.remap = 0;  // two row ranges, or too few chunks / slots for lanes: plain order
+			} else {
+				a.xs_lanes = per_xcd / nsb;
+				const int most = (a.nchunks + kNumXcd - 1) / kNumXcd;  // chunks of the best-served XCD
+				a.nblocks = kNumXcd * ((most + a.xs_lanes - 1) / a.xs_lanes) * nsb * a.xs_lanes;
+			}
+		}
+	};
+	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0, int want_steps = 1) {
+		steps = (want_steps == 2 && kCanTwoSteps) ? 2 : 1;
+		nt = want_nt != 0;
+		if (const char *e = tuning::knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0;
+		cols = (want_cols == 2 && cols2_ok) ? 2 : 1;
+		if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
+		const int valid = cols * kLanes - 2 * steps * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
+		a.nstrips = (d.nx + valid - 1) / valid;
+		plan_mode = one_round;
+		plan_remap = remap;
+		layout();
+	};
+	auto fire = [&]() -> hipError_t {
+		if (c.embed) {
+			if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
+			auto with = [&](auto absorb_c, auto embed_c, auto nt_c) {
+				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, decltype(embed_c)::value, 1, decltype(nt_c)::value>
+				    <<<a.nblocks, block, 0, st>>>(s, a);
+			};
+			auto with_embed = [&](auto absorb_c, auto nt_c) {
+				if (c.embed == 2) with(absorb_c, std::integral_constant<int, 2>{}, nt_c);
+				else with(absorb_c, std::integral_constant<int, 1>{}, nt_c);
+			};
+			auto with_nt = [&](auto absorb_c) {
+				if (nt) with_embed(absorb_c, std::true_type{});
+				else with_embed(absorb_c, std::false_type{});
+			};
+			if (absorb1) with_nt(std::true_type{});
+			else with_nt(std::false_type{});
+			crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
+		} else {
+			// plain step: absorbing rows x columns per lane x store hint x steps per launch, all compile-time
+			auto with = [&](auto absorb_c, auto cols_c, auto nt_c, auto steps_c) {
+				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value,
+				                          kCanTwoSteps ? decltype(steps_c)::value : 1><<<a.nblocks, block, 0, st>>>(s, a);
+			};
+			auto with_steps = [&](auto absorb_c, auto cols_c, auto nt_c) {
+				if (steps == 2) with(absorb_c, cols_c, nt_c, std::integral_constant<int, 2>{});
+				else with(absorb_c, cols_c, nt_c, std::integral_constant<int, 1>{});
+			};
+			auto with_cols = [&](auto absorb_c, auto nt_c) {
+				if (cols == 2) with_steps(absorb_c, std::integral_constant<int, 2>{}, nt_c);
+				else with_steps(absorb_c, std::integral_constant<int, 1>{}, nt_c);
+			};
+			auto with_nt = [&](auto absorb_c) {
+				if (nt) with_cols(absorb_c, std::true_type{});
+				else with_cols(absorb_c, std::false_type{});
+			};
+			auto launch = [&](bool with_selects) {
+				if (with_selects) with_nt(std::true_type{});
+				else with_nt(std::false_type{});
+			};
+			if (steps == 2 && absorb12) {
+				// Two steps per launch with absorbing rows on.  The ABSORB kernel holds the body with the selects AND the one without
+				// (it decides per chunk), and the former's scalar registers spill into two vector registers of the whole kernel: 170
+				// VGPRs, two wavefronts per SIMD instead of three for EVERY item of the launch (+20 ... 38 % measured).  So the rows are
+				// cut: those whose pipeline can meet a global boundary row -- within 2 kApron rows of rows ny - 1 / 0, a band of 18 --
+				// go out first as a launch of their own (ABSORB kernel, 3-row items: it is the items' length, not their number, that
+				// sets such a launch's duration), the rest as launches of the select-free kernel.  Same arithmetic, same bits.
+				const int want[4] = {R[0], R[1], R[2], R[3]};
+				int with_sel[4][2], without[6][2], n_with = 0, n_without = 0;
+				bool fits = true;
+				for (int r = 0; r < 2 && fits; r++) {
+					int cursor = want[2 * r];
+					const int end = want[2 * r + 1];
+					for (int g = -1; g <= 1 && cursor < end; g++) {  // local rows of global rows ny - 1 and 0, one period down / here / one up
+						const int jb = (ny - 1 - js) + g * ny, lo = std::max(cursor, jb - 2 * kApron), hi = std::min(end, jb + 2 + 2 * kApron);
+						if (lo >= hi) continue;
+						if (cursor < lo) {
+							if (n_without == 6) fits = false;
+							else without[n_without][0] = cursor, without[n_without++][1] = lo;
+						}
+						if (n_with == 4) fits = false;
+						else with_sel[n_with][0] = lo, with_sel[n_with++][1] = hi;
+						cursor = hi;
+					}
+					if (cursor < end) {
+						if (n_without == 6) fits = false;
+						else without[n_without][0] = cursor, without[n_without++][1] = end;
+					}
+				}
+				if (!fits || n_with == 0) {
+					launch(true);
+				} else {
+					auto issue = [&](int (*piece)[2], int count, bool selects, int item_rows) {
+						for (int q = 0; q < count; q += 2) {
+							R[0] = piece[q][0];
+							R[1] = piece[q][1];
+							R[2] = q + 1 < count ? piece[q + 1][0] : 0;
+							R[3] = q + 1 < count ? piece[q + 1][1] : 0;
+							chunk_override = item_rows;
+							layout();
+							launch(selects);
+						}
+					};
+					issue(with_sel, n_with, true, 3);
+					issue(without, n_without, false, 0);
+					for (int q = 0; q < 4; q++) R[q] = want[q];
+					chunk_override = 0;
+					layout();
+				}
+			} else {
+				launch(steps == 2 ? absorb12 : absorb1);
+			}
+		}
+		return launch_status();
+	};
+
+	// Launch plan: measured once per context on the first full-size launch (a launch reads one plane set and writes another, so
+	// repeating it is harmless: every candidate writes the same values), then reused for every launch of similar height.
+	FusedPlan *plan = c.plan;
+	const bool plannable = plan && rows2 == 0 && (long)rows * d.nx >= (1L << 20) && !tuning::enabled();  // (under CRD_TUNING the knobs decide)
+	if (plannable && !plan->tuned && plan->autotune) {
+		hipEvent_t e0 = nullptr, e1 = nullptr;
+		// (nothing else may run on the device while candidates are timed: a halo exchange still in flight on the second stream
+		// made a ring context pick a different -- worse -- plan than a plain slab of the same shape)
+		hipError_t err = hipDeviceSynchronize();
+		if (err == hipSuccess) err = hipEventCreate(&e0);
+		if (err == hipSuccess) err = hipEventCreate(&e1);
+		// What a candidate is timed on: with a scratch plane set, launches that step yout -> scratch -> yout -> ... (each reads what
+		// its predecessor wrote, as consecutive steps do); without, repetitions of y0 -> yout.  The difference matters on slabs
+		// small enough for the memory-side cache: an input that is never overwritten stays there, and a plan that keeps its output
+		// out of the caches (non-temporal stores) then looks better than it steps.
+		const bool pingpong = c.tune_scratch.u != nullptr && c.tune_scratch.v != nullptr;
+		auto set_io = [&](const Planes &in, const Planes &out) {
+			a.in_u = row0<Real>(in.u, d.nx);
+			a.in_v = row0<Real>(in.v, d.nx);
+			a.out_u = row0<Real>(out.u, d.nx);
+			a.out_v = row0<Real>(out.v, d.nx);
+		};
+		int flip = 0;
+		auto fire_timed = [&]() -> hipError_t {
+			if (pingpong) {
+				if (flip) set_io(c.tune_scratch, c.yout);
+				else set_io(c.yout, c.tune_scratch);
+				flip ^= 1;
+			}
+			return fire();
+		};
+		if (pingpong && err == hipSuccess) {
+			configure(0, 0, cols_default, 0);
+			err = fire();  // yout holds a state to step on from
+		}
+		// Candidates are timed round-robin, kRounds times, and each keeps its best round: a device's clock drifts while the
+		// measurement runs (a Goldbeter launch sequence lost 15 % over five candidates timed one after the other), and a
+		// candidate must not win or lose by its place in the queue.
+		constexpr int kCandidates = kNumPlanCandidates, kRounds = 3;
+		const bool two_steps_ok = kCanTwoSteps && !c.embed && c.steps == 1 && d.nyl >= 4 * kStepHalo;  // (the caller steps pairs once the plan says so)
+		float t_best[kCandidates];
+		bool live[kCandidates];
+		int reps = 3;
+		for (int k = 0; k < kCandidates; k++) {
+			t_best[k] = 0.f;
+			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt, kPlanCandidates[k].steps);
+			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols, steps));  // (same as a 32-row plan)
+			if (live[k] && kPlanCandidates[k].steps != (two_steps_ok ? steps : 1)) live[k] = false;  // (two steps per launch: plain steps)
+			if (live[k] && steps == 2 && cols == 2 && sizeof(Real) == 8) live[k] = false;  // (256 VGPRs, one wavefront per SIMD: measured 0.347 against 0.312 ms)
+			if (live[k] && kPlanCandidates[k].remap != a.remap) live[k] = false;  // (the mapping fell back to dispatch order)
+			if (live[k] && kPlanCandidates[k].cols != cols) live[k] = false;      // (two columns per lane not possible here, or pinned by a knob)
+			if (live[k] && (kPlanCandidates[k].nt != 0) != nt) live[k] = false;   // (pinned by a knob)
+		}
+		for (int round = 0; round < kRounds && err == hipSuccess; round++)
+			for (int k = 0; err == hipSuccess && k < kCandidates; k++) {
+				if (!live[k]) continue;
+				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt, kPlanCandidates[k].steps);
+				float ms = 0.f;
+				for (int pass = 0; pass < 2 && err == hipSuccess; pass++) {
+					err = fire_timed();  // warm-up of this variant
+					if (err == hipSuccess) err = hipEventRecord(e0, st);
+					for (int r = 0; err == hipSuccess && r < reps; r++) err = fire_timed();
+					if (err == hipSuccess) err = hipEventRecord(e1, st);
+					if (err == hipSuccess) err = hipEventSynchronize(e1);
+					if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+					if (round > 0 || k > 0 || reps > 3 || ms >= 4.0f || ms <= 0.f) break;
+					reps = (int)(12.0f / ms) + 1 < 40 ? (int)(12.0f / ms) + 1 : 40;  // time about four milliseconds' worth per candidate and round, then again
+				}
+				if (err != hipSuccess) break;
+				ms /= (float)(reps * steps);  // per STEP: a two-step launch does twice the work
+				if ((plan->autotune >= 2 || tuning::verbose()))
+					std::fprintf(stderr, "libcrd autotune: %d x %d rows, round %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores, %d step(s) per launch: %.4f ms per step (%d launches timed)\n",
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, nt ? "non-temporal" : "plain", steps, ms, reps);
+				if (t_best[k] == 0.f || ms < t_best[k]) t_best[k] = ms;
+			}
+		// Final: with two dozen candidates a few per cent apart, the fastest of the short bursts above is as often the luckiest as
+		// the best, and a burst runs at clocks a sustained run does not keep.  The plain plan and the three fastest candidates are
+		// therefore timed again, ~16 ms each and twice round, and the final alone decides between them.
+		constexpr int kFinalists = 4, kFinalRounds = 2;
+		int finalist[kFinalists] = {0, -1, -1, -1};
+		for (int f = 1; f < kFinalists; f++)
+			for (int k = 1; k < kCandidates; k++) {
+				if (!live[k] || t_best[k] <= 0.f || k == finalist[1] || k == finalist[2]) continue;
+				if (finalist[f] < 0 || t_best[k] < t_best[finalist[f]]) finalist[f] = k;
+			}
+		float t_final[kFinalists] = {0.f, 0.f, 0.f, 0.f};
+		for (int round = 0; round < kFinalRounds && err == hipSuccess; round++)
+			for (int f = 0; err == hipSuccess && f < kFinalists; f++) {
+				const int k = finalist[f];
+				if (k < 0 || t_best[k] <= 0.f) continue;
+				configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt, kPlanCandidates[k].steps);
+				const int reps2 = (int)(16.0f / t_best[k]) + 1 < 400 ? (int)(16.0f / t_best[k]) + 1 : 400;
+				float ms = 0.f;
+				err = fire_timed();
+				if (err == hipSuccess) err = hipEventRecord(e0, st);
+				for (int r = 0; err == hipSuccess && r < reps2; r++) err = fire_timed();
+				if (err == hipSuccess) err = hipEventRecord(e1, st);
+				if (err == hipSuccess) err = hipEventSynchronize(e1);
+				if (err == hipSuccess) err = hipEventElapsedTime(&ms, e0, e1);
+				if (err != hipSuccess) break;
+				ms /= (float)(reps2 * steps);
+				if ((plan->autotune >= 2 || tuning::verbose()))
+					std::fprintf(stderr, "libcrd autotune: %d x %d rows, final %d, chunk mode %d (%d rows), mapping %d, %d column(s) per lane, %s stores, %d step(s) per launch: %.4f ms per step (%d launches timed)\n",
+					             d.nx, rows, round, kPlanCandidates[k].one_round, a.chunk, a.remap, cols, nt ? "non-temporal" : "plain", steps, ms, reps2);
+				if (t_final[f] == 0.f || ms < t_final[f]) t_final[f] = ms;
+			}
+		int best_k = 0;
+		float base = t_best[0], best = t_best[0];
+		if (t_final[0] > 0.f) {
+			base = best = t_final[0];
+			for (int f = 1; f < kFinalists; f++)
+				if (finalist[f] >= 0 && t_final[f] > 0.f && t_final[f] < best) {
+					best = t_final[f];
+					best_k = finalist[f];
+				}
+		}
+		if (e0) (void)hipEventDestroy(e0);
+		if (e1) (void)hipEventDestroy(e1);
+		set_io(c.y0, c.yout);  // (the launch this call was made for follows below)
+		if (err != hipSuccess) return err;
+		if (best > 0.985f * base) best_k = 0;  // a candidate has to beat the plain plan by more than timing noise
+		plan->tuned = 1;
+		plan->one_round = kPlanCandidates[best_k].one_round;
+		plan->remap = kPlanCandidates[best_k].remap;
+		plan->cols = kPlanCandidates[best_k].cols;
+		plan->nt = kPlanCandidates[best_k].nt;
+		plan->steps = kPlanCandidates[best_k].steps;
+		plan->rows = rows;
+		plan->ms_default = base;
+		plan->ms_best = best_k ? best : base;
+	}
+	// A measured plan applies to the launches it was measured on (heights within a tenth of it: the sweeps of a deep-halo cycle are).
+	// Launches it was not measured on -- edge bands, short ranges -- still take its columns per lane: that choice is about the
+	// kernel's arithmetic, not about the launch's shape.  A PINNED plan (crd_set_launch_plan) is an instruction, not a measurement:
+	// every single-range launch of the context takes all of it, of whatever size (chunk mode and mapping fall back inside configure
+	// where the launch is too small for them), two-range launches its columns per lane and store hint.
+	const bool pinned = plan && plan->tuned && plan->pinned && !tuning::enabled();
+	const bool use_plan = (plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows) || (pinned && rows2 == 0);
+	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default, (use_plan || pinned) ? plan->nt : 0, c.steps);
+	return fire();
+}
+
+}  // namespace
+
+// the fp32 half of launch_fused_step (crd_fused_f32.hip)
+hipError_t launch_fused_step_f32(const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2, hipStream_t s);
+
+}  // namespace crd
