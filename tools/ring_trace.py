@@ -16,10 +16,12 @@ if os.environ.get("MODE", "rccl") == "rccl":
     slab.init_rccl(crd.rccl_unique_id())
 slab.set_stepper("fused")
 # Under the profiler the launch-plan measurement is distorted (every launch pays the tracer): pin the plan the tuner picks for this
-# share outside it -- one-round chunks, one contiguous band per XCD, one column per lane, plain stores -- or PLAN=mode,mapping,cols,nt.
-plan = os.environ.get("PLAN", "1,1,1,0")
+# share outside it -- one-round chunks, one contiguous band per XCD, one column per lane, plain stores -- or PLAN=mode,mapping,cols,nt[,steps].
+plan = os.environ.get("PLAN", "1,1,1,1,2")  # (round 4: two steps per launch; PERIOD = exchange period)
 if plan:
     slab.set_launch_plan(*[int(v) for v in plan.split(",")])
+if os.environ.get("MODE", "rccl") == "rccl" and os.environ.get("PERIOD"):
+    slab.set_exchange_period(int(os.environ["PERIOD"]))
 slab.upload(crd.initial_conditions(crd.run_config(p)))
 slab.step_rk4(0.0, dt, 40)
 slab.synchronize()

@@ -12,7 +12,7 @@ t0 = int(rows[0]["Start_Timestamp"])
 prev_end = t0
 for r in rows:
     s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("crd::(anonymous namespace)::", "")[:48]
+    name = r["Kernel_Name"].replace("void ", "").replace("crd::(anonymous namespace)::", "").split("(")[0][:64]
     print("%10.1f us  dur %8.1f  gap %7.1f  q=%s grid=%s  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, r.get("Queue_Id", "?"),
                                                             r.get("Grid_Size_X", r.get("Grid_Size", "?")), name))
     prev_end = max(prev_end, e)
