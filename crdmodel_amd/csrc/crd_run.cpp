@@ -337,6 +337,24 @@ int main(int argc, char *argv[])
 		}
 	}
 
+	// The one-launch stepper measures its launch plan on a context's first full-size step (~0.7 s at 8192^2): done here, ahead of the
+	// first output interval, so that the rate line below is the stepping's and nothing else's.  (The error-controlled integrators
+	// measure theirs inside their first attempt.)
+	if (!cfg.adaptive) {
+		const auto plan_t0 = std::chrono::steady_clock::now();
+		for (int k = 0; k < G; k++)
+			if ((rc = crd_plan_launches(ctx[(size_t)k])) != CRD_OK) {
+				die("crd_plan_launches", rc, ctx[(size_t)k]);
+				cleanup();
+				return 1;
+			}
+		const double plan_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - plan_t0).count();
+		crd_launch_plan lp;
+		if (!o.quiet && crd_get_launch_plan(ctx[0], &lp) == CRD_OK && lp.tuned)
+			std::printf("   launch plan (measured in %.2f s): chunk mode %d, XCD mapping %d, %d column(s) per lane, %s stores, %d step(s) per launch\n", plan_s, lp.one_round,
+			            lp.xcd_mapping, lp.columns_per_lane, lp.nontemporal_stores ? "non-temporal" : "plain", lp.steps_per_launch);
+	}
+
 	int status = 0;
 	double adaptive_h = 0.0;
 	long long adaptive_steps = 0, adaptive_rejected = 0;
@@ -428,9 +446,11 @@ int main(int argc, char *argv[])
 	if (!o.quiet && steps_taken > 0 && stepping_s > 0.0) {
 		// compulsory-byte model of a step: both fields read once and written once (the one-launch stepper's traffic; the four
 		// stage kernels move 8 x that)
-		const double points = (double)g.nx * (double)g.ny, bytes_per_point_step = 4.0 * (double)value_bytes;
+		crd_launch_plan lp{};
+		const bool pairs = !cfg.adaptive && crd_get_launch_plan(ctx[0], &lp) == CRD_OK && lp.tuned && lp.steps_per_launch == 2;
+		const double points = (double)g.nx * (double)g.ny, bytes_per_point_step = 4.0 * (double)value_bytes / (pairs ? 2.0 : 1.0);  // (two steps per launch: the state crosses memory once per two)
 		char line[256];
-		std::snprintf(line, sizeof line, "\n   rate: %lld steps in %.3f s of stepping = %.1f steps/s, %.4g grid-point-steps/s, %.1f GB/s (%g B per point-step)",
+		std::snprintf(line, sizeof line, "\n   rate: %lld steps in %.6f s of stepping = %.1f steps/s, %.4g grid-point-steps/s, %.1f GB/s (%g B per point-step)",
 		              steps_taken, stepping_s, (double)steps_taken / stepping_s, points * (double)steps_taken / stepping_s,
 		              points * (double)steps_taken * bytes_per_point_step / stepping_s / 1e9, bytes_per_point_step);
 		std::cout << line;
