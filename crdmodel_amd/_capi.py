@@ -84,6 +84,7 @@ class RunConfig(C.Structure):
         ("n_gpus", C.c_int32), ("stepper", C.c_int32),
         ("adaptive", C.c_int32), ("steady_state_decimals", C.c_int32),
         ("rtol", C.c_double), ("atol", C.c_double),
+        ("exchange_period", C.c_int32), ("reserved", C.c_int32),
     ]
 
 

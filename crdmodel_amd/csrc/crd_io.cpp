@@ -211,6 +211,7 @@ extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd
 	if (ok && ini.has("Solver.stepper")) I("Solver.stepper", &cfg->stepper);
 	if (ok && ini.has("Solver.adaptive")) I("Solver.adaptive", &cfg->adaptive);
 	if (ok && ini.has("Solver.steadyStateDigits")) I("Solver.steadyStateDigits", &cfg->steady_state_decimals);
+	if (ok && ini.has("Solver.exchangePeriod")) I("Solver.exchangePeriod", &cfg->exchange_period);
 	if (ok && ini.has("Solver.rtol")) ok = ini.get_double("Solver.rtol", &cfg->rtol, &why);
 	if (ok && ini.has("Solver.atol")) ok = ini.get_double("Solver.atol", &cfg->atol, &why);
 	if (ok && ini.has("Solver.precision")) {
@@ -238,6 +239,10 @@ extern "C" int crd_config_load_ini(const char *path, int model, int surface, crd
 	}
 	if (cfg->adaptive < 0 || cfg->adaptive > 2) {
 		set_err(err, err_len, "Solver.adaptive must be 0 (fixed step), 1 (ARKode-style) or 2 (RK4(3))");
+		return CRD_EINVAL;
+	}
+	if (cfg->exchange_period != 0 && (cfg->exchange_period < 3 || cfg->exchange_period > 16)) {
+		set_err(err, err_len, "Solver.exchangePeriod must be 0 (automatic) or 3 .. 16");
 		return CRD_EINVAL;
 	}
 	if (cfg->steady_state_decimals < 0 || cfg->steady_state_decimals > 17) {

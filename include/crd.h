@@ -105,6 +105,9 @@ typedef struct crd_run_config {
 	                                * array (n digits behind the decimal point; numpy's default is 8) and fscanf
 	                                * (crd_steady_state_as_printed) */
 	double rtol, atol;        /* [Solver] rtol / atol, defaults 1e-5 / 1e-10 (src/FHNmodel_torus.cpp:197-198) */
+	int32_t exchange_period;  /* [Solver] exchangePeriod: fused steps between two halo exchanges of a multi-slab run (crd_set_exchange_period, 3 .. 16);
+	                           * 0 (default) = the driver chooses: 16 where every slab has at least 256 rows, else 8 */
+	int32_t reserved;
 } crd_run_config;
 
 typedef struct crd_ctx crd_ctx;

@@ -126,6 +126,14 @@ def test_goldbeter_steady_state_as_the_reference_reads_it(tmp_path):
     bad.write_text(base + "\n[Solver]\nsteadyStateDigits = 40\n")
     with pytest.raises(crd._capi.CrdError):
         crd.load_ini(bad, "goldbeter", "torus")
+    # [Solver] exchangePeriod (round 4): 0 / absent = the driver chooses, 3 .. 16 = crd_set_exchange_period for every slab of the run
+    assert cfg.exchange_period == 0
+    ini.write_text(base + "\n[Solver]\nexchangePeriod = 12\n")
+    assert crd.load_ini(ini, "goldbeter", "torus").exchange_period == 12
+    for v in (2, 17, -1):
+        bad.write_text(base + "\n[Solver]\nexchangePeriod = %d\n" % v)
+        with pytest.raises(crd._capi.CrdError):
+            crd.load_ini(bad, "goldbeter", "torus")
 
 
 IC_CASES = [
