@@ -35,6 +35,7 @@ struct Options {
 	bool binary_only = false;  // ... and no text rows (the text files are created empty; only crdmodel_amd.post reads such a run)
 	bool ref_steady_state = false;  // Goldbeter rest state as the reference reads it from its script's print (8 decimals)
 	int d0 = 0, d1 = 0;  // --decomp d0xd1: the reference's 2-D block layout (theta x phi) instead of phi-slabs; "--decomp mpi" = MPI_Dims_create(gpus)
+	bool block_contexts = false;  // --block-contexts: also COMPUTE on those blocks (staged kernels); default: files in that layout, computed on phi-slabs
 	bool decomp_mpi = false;
 };
 
@@ -45,7 +46,7 @@ struct Options {
 	} else {
 		std::cerr << "Usage: " << argv0
 		          << " --model fhn|goldbeter --surface torus|flat [--gpus G] [--devices D] [--dt DT] [--stepper auto|staged|fused]\n"
-		             "       [--precision 64|32] [--adaptive|--adaptive-rk43|--fixed] [--binary|--binary-only] [--ref-steady-state] [--decomp D0xD1|mpi]\n"
+		             "       [--precision 64|32] [--adaptive|--adaptive-rk43|--fixed] [--binary|--binary-only] [--ref-steady-state] [--decomp D0xD1|mpi [--block-contexts]]\n"
 		             "       [--outdir DIR] [--quiet]\n"
 		             "       <Config file path>\n";
 	}
@@ -181,6 +182,7 @@ int main(int argc, char *argv[])
 			else if (s == "--binary") o.binary = true;
 			else if (s == "--binary-only") o.binary = o.binary_only = true;
 			else if (s == "--ref-steady-state") o.ref_steady_state = true;
+			else if (s == "--block-contexts") o.block_contexts = true;
 			else if (s == "--decomp") {
 				const std::string v = next();
 				if (v == "mpi") o.decomp_mpi = true;
@@ -231,18 +233,28 @@ int main(int argc, char *argv[])
 
 	crd_grid g;
 	if ((rc = crd_grid_from_params(&cfg.params, &g)) != CRD_OK) return die("crd_grid_from_params", rc, nullptr);
-	// Decomposition: phi-slabs (1 x G: the layout for one node, and the one the one-launch stepper needs) unless the reference's
-	// own 2-D blocks are asked for -- `--decomp 2x2`, or `--decomp mpi` = what MPI_Dims_create makes of the slab count
-	// (src/FHNmodel_torus.cpp:724-728: `mpirun -np 4` is 2 x 2) -- which step with the staged kernels.
-	int d0 = 1, d1 = cfg.n_gpus;
-	if (o.decomp_mpi) crd_dims_create(cfg.n_gpus, &d0, &d1);
+	// Two decompositions.  FILES: phi-slabs (1 x gpus) unless the reference's own 2-D blocks are asked for -- `--decomp 2x2`, or
+	// `--decomp mpi` = what MPI_Dims_create makes of the slab count (src/FHNmodel_torus.cpp:724-728: `mpirun -np 4` is 2 x 2): the file
+	// sets, subdomain headers and (for the rand() rule) initial conditions of that process grid.  COMPUTE: phi-slabs, one per GPU (the
+	// layout for one node, and the one the one-launch stepper, the error-controlled integrators and the deep halo need) -- also
+	// under --decomp (round 4): the blocks' rows are cut out of the slabs' frames at output time; `--block-contexts` computes on
+	// the 2-D blocks themselves instead (staged kernels, fixed step, text files), bit-equal to the whole domain's staged run.
+	int fd0 = 1, fd1 = cfg.n_gpus;  // the files' process grid
+	if (o.decomp_mpi) crd_dims_create(cfg.n_gpus, &fd0, &fd1);
 	else if (o.d0 > 0) {
-		d0 = o.d0;
-		d1 = o.d1;
+		fd0 = o.d0;
+		fd1 = o.d1;
 	}
+	const int F = fd0 * fd1;
+	const bool recut = fd0 > 1 && !o.block_contexts;  // files in a layout the contexts do not have
+	const int d0 = recut ? 1 : fd0, d1 = recut ? cfg.n_gpus : fd1;  // the contexts' decomposition
 	const int G = d0 * d1;
-	if (d0 > 1 && (cfg.adaptive || o.binary)) {
-		std::cerr << "\nCRD_ERROR: theta-blocks (--decomp with more than one theta-block) step with the fixed-step staged RK4 and write text files only\n\n";
+	if (fd0 > 1 && o.binary) {
+		std::cerr << "\nCRD_ERROR: the .npy side-channel holds phi-slab frames: not available with theta-blocks (--decomp with more than one theta-block)\n\n";
+		return 1;
+	}
+	if (d0 > 1 && cfg.adaptive) {
+		std::cerr << "\nCRD_ERROR: theta-block contexts (--block-contexts) step with the fixed-step staged RK4 and write text files only\n\n";
 		return 1;
 	}
 	const int ndev = o.devices > 0 ? o.devices : G;
@@ -260,7 +272,27 @@ int main(int argc, char *argv[])
 	const double dt = dTout / (double)steps_per_output;
 
 	std::vector<crd_ctx *> ctx((size_t)G, nullptr);
-	std::vector<crd_writer *> wr((size_t)G, nullptr);
+	std::vector<crd_writer *> wr((size_t)F, nullptr);
+	// recut: the frames of the F file blocks, cut out of the G slabs' frames (two sets, like the slabs' own)
+	std::vector<std::vector<double>> fhost((size_t)(recut ? F : 0)), fhost_b((size_t)(recut ? F : 0));
+	struct Rect {
+		int64_t is, ie, js, je;
+	};
+	std::vector<Rect> frect((size_t)F), crect((size_t)G);
+	// copy between the slabs' AoS frames (full width, rows cjs .. cje) and the blocks' (columns is .. ie of rows js .. je)
+	auto recut_frames = [&](std::vector<std::vector<double>> &slabs, std::vector<std::vector<double>> &blocks, bool to_blocks) {
+		for (int f = 0; f < F; f++) {
+			const Rect &b = frect[(size_t)f];
+			const int64_t nxl = b.ie - b.is + 1;
+			for (int64_t j = b.js; j <= b.je; j++) {
+				int c = 0;
+				while (c + 1 < G && j > crect[(size_t)c].je) c++;
+				double *slab_row = slabs[(size_t)c].data() + 2 * ((j - crect[(size_t)c].js) * g.nx + b.is), *block_row = blocks[(size_t)f].data() + 2 * (j - b.js) * nxl;
+				if (to_blocks) std::memcpy(block_row, slab_row, (size_t)(2 * nxl) * sizeof(double));
+				else std::memcpy(slab_row, block_row, (size_t)(2 * nxl) * sizeof(double));
+			}
+		}
+	};
 	// Two host copies of every slab: while the writer thread formats output k from one, the GPU integrates towards
 	// output k+1 and downloads into the other (text output of a large grid costs more than the steps between outputs).
 	std::vector<std::vector<double>> host((size_t)G), host_b((size_t)G);
@@ -311,29 +343,44 @@ int main(int argc, char *argv[])
 			}
 	}
 
-	int64_t is0 = 0, ie0 = 0, js0 = 0, je0 = 0;
-	crd_get_block(ctx[0], &is0, &ie0, &js0, &je0);
-	if (!o.quiet) banner(cfg, g, G, ie0 - is0 + 1, je0 - js0 + 1, s0, s1, dt, steps_per_output);
+	for (int k = 0; k < G; k++) crd_get_block(ctx[(size_t)k], &crect[(size_t)k].is, &crect[(size_t)k].ie, &crect[(size_t)k].js, &crect[(size_t)k].je);
+	for (int f = 0; f < F; f++) {
+		if (recut) crd_block_extents(g.nx, g.ny, f / fd1, fd0, f % fd1, fd1, &frect[(size_t)f].is, &frect[(size_t)f].ie, &frect[(size_t)f].js, &frect[(size_t)f].je);
+		else frect[(size_t)f] = crect[(size_t)f];
+	}
+	if (!o.quiet) banner(cfg, g, F, frect[0].ie - frect[0].is + 1, frect[0].je - frect[0].js + 1, s0, s1, dt, steps_per_output);
 
-	// Initial conditions, subdomain files, first output row (src/FHNmodel_torus.cpp:285-354,376-410).
+	// Initial conditions, subdomain files, first output row (src/FHNmodel_torus.cpp:285-354,376-410).  The initial conditions are
+	// those of the FILES' process grid (the rand() rule draws block by block, as every reference rank does); recut: the blocks'
+	// frames are then laid into the slabs' for the upload.
 	for (int k = 0; k < G; k++) {
-		int64_t is, ie, js, je;
-		crd_get_block(ctx[(size_t)k], &is, &ie, &js, &je);
-		host[(size_t)k].resize((size_t)(2 * (ie - is + 1) * (je - js + 1)));
+		host[(size_t)k].resize((size_t)(2 * (crect[(size_t)k].ie - crect[(size_t)k].is + 1) * (crect[(size_t)k].je - crect[(size_t)k].js + 1)));
 		host_b[(size_t)k].resize(host[(size_t)k].size());
-		if ((rc = crd_initial_conditions_block(&cfg, is, ie, js, je, host[(size_t)k].data())) != CRD_OK) {
+	}
+	for (int f = 0; f < F; f++) {
+		const Rect &b = frect[(size_t)f];
+		std::vector<double> &ic = recut ? fhost[(size_t)f] : host[(size_t)f];
+		if (recut) {
+			fhost[(size_t)f].resize((size_t)(2 * (b.ie - b.is + 1) * (b.je - b.js + 1)));
+			fhost_b[(size_t)f].resize(fhost[(size_t)f].size());
+		}
+		if ((rc = crd_initial_conditions_block(&cfg, b.is, b.ie, b.js, b.je, ic.data())) != CRD_OK) {
 			die("crd_initial_conditions", rc, nullptr);
 			cleanup();
 			return 1;
 		}
-		if ((rc = crd_state_upload(ctx[(size_t)k], host[(size_t)k].data(), 1)) != CRD_OK) {
-			die("crd_state_upload", rc, ctx[(size_t)k]);
+		if ((rc = crd_writer_open_block(&cfg, o.outdir.c_str(), f, f / fd1, fd0, f % fd1, fd1, &wr[(size_t)f])) != CRD_OK ||
+		    (!o.binary_only && (rc = crd_writer_write_row(wr[(size_t)f], ic.data())) != CRD_OK)) {
+			die("crd_writer", rc, nullptr);
 			cleanup();
 			return 1;
 		}
-		if ((rc = crd_writer_open_block(&cfg, o.outdir.c_str(), k, k / d1, d0, k % d1, d1, &wr[(size_t)k])) != CRD_OK ||
-		    (!o.binary_only && (rc = crd_writer_write_row(wr[(size_t)k], host[(size_t)k].data())) != CRD_OK)) {
-			die("crd_writer", rc, nullptr);
+	}
+	if (recut) recut_frames(host, fhost, false);
+	for (int k = 0; k < G; k++) {
+		const int64_t js = crect[(size_t)k].js, je = crect[(size_t)k].je;
+		if ((rc = crd_state_upload(ctx[(size_t)k], host[(size_t)k].data(), 1)) != CRD_OK) {
+			die("crd_state_upload", rc, ctx[(size_t)k]);
 			cleanup();
 			return 1;
 		}
@@ -436,12 +483,14 @@ int main(int argc, char *argv[])
 			crd_trace_range_pop();
 			break;
 		}
-		writer = std::thread([&wr, &buf, &writer_rc, &npy, &frame, &o, G, set, nvars_out]() {
-			for (int k = 0; k < G && writer_rc == CRD_OK; k++) {
+		auto &fbuf = (iout & 1) ? fhost_b : fhost;
+		writer = std::thread([&wr, &buf, &fbuf, &writer_rc, &npy, &frame, &o, &recut_frames, G, F, recut, set, nvars_out]() {
+			for (int k = 0; k < G && writer_rc == CRD_OK; k++)
 				for (int v = 0; o.binary && v < nvars_out && writer_rc == CRD_OK; v++)
 					writer_rc = crd_npy_writer_append(npy[(size_t)(2 * k + v)], frame[(size_t)(4 * k + 2 * v + set)]);
-				if (!o.binary_only && writer_rc == CRD_OK) writer_rc = crd_writer_write_row(wr[(size_t)k], buf[(size_t)k].data());
-			}
+			if (recut && !o.binary_only) recut_frames(buf, fbuf, true);  // the file blocks' frames out of the slabs' (on the writer's time)
+			for (int f = 0; f < F && !o.binary_only && writer_rc == CRD_OK; f++)
+				writer_rc = crd_writer_write_row(wr[(size_t)f], (recut ? fbuf : buf)[(size_t)f].data());
 		});
 
 		// progress line, src/FHNmodel_torus.cpp:457-477

@@ -114,28 +114,50 @@ def test_driver_adaptive_mode(gpu_device, tmp_path):
     assert rel_err(u3, np.stack(frames)[..., 0]) <= 1e-9
 
 
-@pytest.mark.parametrize("decomp", ["2x2", "mpi"])
+@pytest.mark.parametrize("decomp", [("2x2",), ("mpi",), ("2x2", "--block-contexts"), ("2x2", "--gpus", "1"), ("2x2", "--gpus", "3")])
 def test_driver_writes_the_references_np4_block_layout(gpu_device, tmp_path, decomp):
     """`crd_run --gpus 4 --decomp 2x2` (or `--decomp mpi`: MPI_Dims_create of the slab count): the four file sets of the
     reference's `mpirun -np 4` run (util/ShellScripts/runFHNmodelTorus.sh:6) -- subdomain headers with the 2 x 2 extents of
-    SetupDecomp, rows of nyl * nxl values per block -- stitched by the plot script's loader logic and compared with the oracle."""
+    SetupDecomp, rows of nyl * nxl values per block -- stitched by the plot script's loader logic and compared with the oracle.
+    The files' layout is not the computation's: the run steps on phi-slabs (any number of them: 4, 1, 3) and cuts the blocks out
+    of their frames; `--block-contexts` computes on the 2 x 2 blocks themselves (staged kernels)."""
     cfg = crd.load_ini(INI, "fhn", "torus")
-    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--gpus", "4", "--devices", "1", "--decomp", decomp, INI], cwd=tmp_path,
+    argv = ["--gpus", "4", "--devices", "1", "--decomp"] + list(decomp)  # (a later --gpus overrides the first)
+    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus"] + argv + [INI], cwd=tmp_path,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
     assert "nprocs = 4" in r.stdout and "nxl = 8" in r.stdout and "nyl = 20" in r.stdout
     for rank, (c0, c1) in enumerate([(0, 0), (0, 1), (1, 0), (1, 1)]):
         hdr = open(tmp_path / ("FHNmodel_torus_subdomain.%03d.txt" % rank)).read().split()
         assert tuple(int(v) for v in hdr[:6]) == (16, 40) + crd.block_extents(16, 40, c0, 2, c1, 2)
+    assert not (tmp_path / "FHNmodel_torus_subdomain.004.txt").exists()
     want = oracle_outputs(cfg)
     u, meta = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "u")
     v, _ = load_like_the_plot_script(tmp_path, "FHNmodel_torus", "v")
     assert meta["nprocs"] == 4 and u.shape == want[..., 0].shape
     assert np.array_equal(u[0], want[0, ..., 0]) and rel_err(u, want[..., 0]) <= 1e-9 and rel_err(v, want[..., 1]) <= 1e-9
-    # what the block layout does not do is refused up front
-    r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--gpus", "4", "--decomp", "2x2", "--adaptive", INI], cwd=tmp_path,
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 1 and "theta-blocks" in r.stderr
+
+
+def test_driver_block_layout_with_the_error_controlled_integrator(gpu_device, tmp_path):
+    """The block FILE layout no longer limits the integrator: `--decomp 2x2 --adaptive` writes, block by block, the very numbers
+    the phi-slab run of the same integrator writes (same slabs underneath: the files are cut out of the same frames).  What
+    still needs the slab layout is refused up front: block CONTEXTS with an error-controlled integrator, .npy frames of blocks."""
+    run = [os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--gpus", "2", "--devices", "1", "--adaptive", "--quiet"]
+    (tmp_path / "slabs").mkdir()
+    (tmp_path / "blocks").mkdir()
+    r = subprocess.run(run + [INI], cwd=tmp_path / "slabs", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    r = subprocess.run(run + ["--decomp", "2x2", INI], cwd=tmp_path / "blocks", capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    for name in ("u", "v"):
+        a, ma = load_like_the_plot_script(tmp_path / "slabs", "FHNmodel_torus", name)
+        b, mb = load_like_the_plot_script(tmp_path / "blocks", "FHNmodel_torus", name)
+        assert (ma["nprocs"], mb["nprocs"]) == (2, 4) and np.array_equal(a, b)
+        assert np.abs(a[-1] - a[0]).max() > 0.1
+    for extra, word in ((["--block-contexts", "--adaptive"], "theta-block contexts"), (["--binary"], "theta-blocks")):
+        r = subprocess.run([os.path.join(BIN, "crd_run"), "--model", "fhn", "--surface", "torus", "--gpus", "4", "--decomp", "2x2"] + extra + [INI],
+                           cwd=tmp_path, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 1 and word in r.stderr, r.stderr
 
 
 def test_driver_stops_when_any_slab_blows_up(gpu_device, tmp_path):
