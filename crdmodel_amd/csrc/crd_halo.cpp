@@ -1,6 +1,8 @@
 // crd_halo.cpp -- the RCCL binding and the halo transports of multi-slab runs.  Host code only.
 #include <dlfcn.h>
 
+#include <cstdlib>
+
 #include <mutex>
 
 #include "crd_ctx.h"
@@ -15,9 +17,17 @@ bool RcclApi::load()
 	std::lock_guard<std::mutex> lock(once);
 	if (handle) return true;
 	if (!error.empty()) return false;
+	// CRD_RCCL_LIBRARY: bind this library instead (another RCCL build; the multi-process ring tests' stand-in, tests/native)
+	if (const char *named = std::getenv("CRD_RCCL_LIBRARY"); named && *named) {
+		handle = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+		if (!handle) {
+			error = std::string("cannot load CRD_RCCL_LIBRARY: ") + dlerror();
+			return false;
+		}
+	}
 	for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
-		handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
 		if (handle) break;
+		handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
 	}
 	if (!handle) {
 		error = std::string("cannot load librccl: ") + dlerror();
