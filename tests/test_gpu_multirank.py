@@ -156,3 +156,24 @@ def test_a_rank_that_stays_away_is_an_error_not_a_hang(gpu_device, standin, tmp_
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "ring_rank_worker.py"), "0", "2", unique_id(standin).hex(), str(spec_path), str(tmp_path / "r0.npz")],
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "not every rank called ncclCommInitRank" in (r.stdout + r.stderr)
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_bench_with_rank_processes_on_one_gpu(gpu_device, standin, world):
+    """`python bench.py --gpus N` end to end with N REAL rank processes of the shipped library (the self-launcher, the gloo control
+    plane, communicator set-up from a broadcast id, the halo self-check across ranks, the exchange-period and slack rehearsals, the
+    per-rank gather, the JSON line) -- the ranks share the box's one GPU and the stand-in transport moves the halos, which the
+    line says (`config.halo.rccl_library_override`): a rehearsal of the control flow, not a figure."""
+    env = dict(os.environ, CRD_RCCL_LIBRARY=standin, CRD_STANDIN_TIMEOUT_S="60")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--transport", "rccl", "--size", "2048", "--steps", "24", "--warmup", "6",
+                        "--repeats", "1", "--no-cpu-baseline"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    halo = d["config"]["halo"]
+    assert d["n_gpus"] == world and d["steps"] == 24 and d["value"] > 0 and d["scaling"] == "strong"
+    assert halo["transport"] == "rccl" and halo["rccl_comm_count"] == world and halo["rccl_library_override"] == standin
+    assert halo["halo_selfcheck"]["ok"] and halo["halo_selfcheck"]["mismatching_values"] == 0
+    assert d["config"]["decomposition"] == "phi-slabs x%d" % world and len(d["per_rank"]) == world
+    assert d["config"]["launcher"]["transports_tried"] == ["rccl"]
