@@ -406,8 +406,11 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			const int q = (int)((s + q0) % E);
 			const int nsub = (pairs && s + 2 <= nsteps && q + 2 <= E && pair_is_exact(lead, t0, s, dt)) ? 2 : 1;
 			// time one launch of the dominant kernel mid-run (fused: a launch of the cycle that is one full-height sweep, i.e. neither
-			// the split first nor the split last one, nor the one that finishes a deferred first)
-			const bool middle = q >= (lead->halo_slack >= 2 ? 2 * nsub : 1) && q + nsub < E;
+			// the split first nor the split last one, nor the one that finishes a first whose ghost readers were deferred -- whatever
+			// the two launches take, one step or two)
+			bool finishes_deferred = false;
+			for (int k = 0; k < n; k++) finishes_deferred = finishes_deferred || cs[k]->ghost_deferred;
+			const bool middle = q >= 1 && q + nsub < E && !finishes_deferred;
 			const bool timed_step = timed_launches && !timed && (fused ? (middle && (s >= nsteps / 2 || s + E >= nsteps)) : s >= nsteps / 2);
 			const double t = t0 + (double)s * dt;
 			if (fused) {

@@ -27,14 +27,18 @@ NATIVE = os.path.join(ROOT, "tests", "native")
 STANDIN = os.path.join(NATIVE, "_build", "libring_standin_rccl.so")
 
 
-@pytest.fixture(scope="module")
-def standin():
+def build_standin():
     src = os.path.join(NATIVE, "ring_standin_rccl.cpp")
     if not os.path.exists(STANDIN) or os.path.getmtime(STANDIN) < os.path.getmtime(src):
         hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
         os.makedirs(os.path.dirname(STANDIN), exist_ok=True)
         subprocess.run([hipcc, "-O2", "-std=c++17", "-fPIC", "-shared", src, "-o", STANDIN, "-lpthread", "-lrt"], check=True, capture_output=True)
     return STANDIN
+
+
+@pytest.fixture(scope="module")
+def standin():
+    return build_standin()
 
 
 def unique_id(standin):
