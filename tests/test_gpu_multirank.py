@@ -51,18 +51,25 @@ def unique_id(standin):
 def run_ring(standin, spec, world, tmp_path):
     spec_path = tmp_path / "programme.json"
     spec_path.write_text(json.dumps(spec))
-    ident = unique_id(standin).hex()
+    raw_id = unique_id(standin)
+    ident = raw_id.hex()
     env = dict(os.environ, CRD_RCCL_LIBRARY=standin, CRD_STANDIN_TIMEOUT_S="40")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ring_rank_worker.py"), str(r), str(world), ident, str(spec_path), str(tmp_path / ("rank%d.npz" % r))],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
-    for pr in procs:
-        try:
-            outs.append(pr.communicate(timeout=240)[0])
-        except subprocess.TimeoutExpired:
-            for q in procs:
-                q.kill()
-            raise
+    try:
+        for pr in procs:
+            try:
+                outs.append(pr.communicate(timeout=240)[0])
+            except subprocess.TimeoutExpired:
+                for q in procs:
+                    q.kill()
+                raise
+    finally:
+        # a rank that died before ncclCommDestroy leaves the ring's shared-memory segment behind (it lives in memory): remove it
+        segment = os.path.join("/dev/shm", raw_id.split(b"\0", 1)[0].decode().lstrip("/"))
+        if os.path.exists(segment):
+            os.unlink(segment)
     assert all(pr.returncode == 0 for pr in procs), "\n".join(o[-3000:] for o in outs)
     parts = [np.load(tmp_path / ("rank%d.npz" % r)) for r in range(world)]
     n_shots = len([k for k in parts[0].files if k.startswith("shot")])
