@@ -135,6 +135,7 @@ _SIGNATURES = {
     "crd_get_grid": (C.c_int, [_vp, C.POINTER(Grid)]),
     "crd_get_slab": (C.c_int, [_vp, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "crd_comm_attach_local": (C.c_int, [C.POINTER(_vp), C.c_int]),
+    "crd_comm_set_rccl_library": (C.c_int, [C.c_char_p]),
     "crd_comm_unique_id": (C.c_int, [_vp]),
     "crd_comm_init_rccl": (C.c_int, [_vp, _vp]),
     "crd_comm_info": (C.c_int, [_vp, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
@@ -225,6 +226,9 @@ def lib():
             fn.argtypes = args
         if L.crd_abi_version() != ABI_VERSION:
             raise ImportError("libcrd.so ABI version mismatch")
+        if os.environ.get("CRD_RCCL_LIBRARY"):  # another RCCL build / the multi-process ring tests' stand-in (tests/native)
+            if L.crd_comm_set_rccl_library(os.environ["CRD_RCCL_LIBRARY"].encode()) != OK:
+                raise ImportError("crd_comm_set_rccl_library failed")
         _lib = L
     return _lib
 

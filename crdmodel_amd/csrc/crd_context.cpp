@@ -359,6 +359,14 @@ int crd_comm_attach_local(crd_ctx *const *ctxs, int n)
 	return CRD_OK;
 }
 
+int crd_comm_set_rccl_library(const char *path)
+{
+	if (g_rccl.handle) return fail(nullptr, CRD_ESTATE, "the RCCL entry points are already bound");
+	g_rccl.library = path ? path : "";
+	g_rccl.error.clear();
+	return CRD_OK;
+}
+
 int crd_comm_unique_id(void *id128)
 {
 	if (!id128) return CRD_EINVAL;

@@ -35,6 +35,7 @@ struct RcclApi {
 	decltype(&ncclCommUserRank) CommUserRank = nullptr;
 	decltype(&ncclGetErrorString) GetErrorString = nullptr;
 	std::string error;
+	std::string library;  // crd_comm_set_rccl_library: bind this file instead of librccl.so.1
 
 	bool load();  // crd_halo.cpp
 };

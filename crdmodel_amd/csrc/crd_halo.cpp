@@ -1,8 +1,6 @@
 // crd_halo.cpp -- the RCCL binding and the halo transports of multi-slab runs.  Host code only.
 #include <dlfcn.h>
 
-#include <cstdlib>
-
 #include <mutex>
 
 #include "crd_ctx.h"
@@ -17,11 +15,11 @@ bool RcclApi::load()
 	std::lock_guard<std::mutex> lock(once);
 	if (handle) return true;
 	if (!error.empty()) return false;
-	// CRD_RCCL_LIBRARY: bind this library instead (another RCCL build; the multi-process ring tests' stand-in, tests/native)
-	if (const char *named = std::getenv("CRD_RCCL_LIBRARY"); named && *named) {
-		handle = dlopen(named, RTLD_NOW | RTLD_LOCAL);
+	// crd_comm_set_rccl_library: bind that library instead (another RCCL build; the multi-process ring tests' stand-in, tests/native)
+	if (!library.empty()) {
+		handle = dlopen(library.c_str(), RTLD_NOW | RTLD_LOCAL);
 		if (!handle) {
-			error = std::string("cannot load CRD_RCCL_LIBRARY: ") + dlerror();
+			error = std::string("cannot load ") + library + ": " + dlerror();
 			return false;
 		}
 	}

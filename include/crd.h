@@ -217,8 +217,10 @@ int crd_get_slab(const crd_ctx *ctx, int64_t *js, int64_t *je);
 /* Multi-slab wiring.  LOCAL: give every context of the run the full array (same process).
  * RCCL: rank r of n_slabs ranks calls crd_comm_init_rccl with the 128-byte id rank 0 obtained from
  * crd_comm_unique_id and distributed by any means (MPI_Bcast, torch.distributed, a file).  The RCCL entry points are bound at
- * first use from librccl.so.1, or from the library CRD_RCCL_LIBRARY names in the environment. */
+ * first use from librccl.so.1 -- or from the file given to crd_comm_set_rccl_library before that first use (another RCCL
+ * build; NULL or "" = the default again; CRD_ESTATE once bound). */
 int crd_comm_attach_local(crd_ctx *const *ctxs, int n_slabs);
+int crd_comm_set_rccl_library(const char *path);
 int crd_comm_unique_id(void *id128);
 int crd_comm_init_rccl(crd_ctx *ctx, const void *id128);
 

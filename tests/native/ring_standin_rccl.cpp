@@ -3,8 +3,8 @@
 // RCCL refuses two ranks on one device ("Duplicate GPU detected"), and the development box has one GPU, so the product's
 // multi-rank protocol (halo exchange order, exchange-cycle agreement, the error norm's all-reduce, the resume vote) had only
 // ever met world size 1 on hardware.  This library exports the eleven entry points libcrd binds (crd_halo.cpp, RcclApi::load)
-// and moves the bytes through a POSIX shared-memory segment instead of xGMI.  libcrd loads it when CRD_RCCL_LIBRARY names it;
-// nothing else changes: every kernel, stream, event and host decision of the ring path is the product's.
+// and moves the bytes through a POSIX shared-memory segment instead of xGMI.  libcrd binds it when crd_comm_set_rccl_library names
+// it (the Python package: CRD_RCCL_LIBRARY in the environment); nothing else changes: every kernel, stream, event and host decision of the ring path is the product's.
 //
 // Semantics kept from NCCL: the k-th send from rank a to rank b pairs with the k-th receive at b from a; the operations of a
 // group complete together; an all-reduce is one call per rank in the same order; everything is ordered behind the work already
