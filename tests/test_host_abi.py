@@ -466,3 +466,29 @@ def test_initial_wave_and_beta_ramp_are_what_the_parameter_files_document():
     yy[..., 0], yy[..., 1] = 0.3, -0.2
     b = co.rhs(op, 1e9, yy)[:, 5, 1] / 0.36 - 0.3
     assert abs(b[0] - 0.7) <= 1e-12 and abs(b[-1] - 1.7) <= 1e-12 and np.max(np.abs(np.diff(b, 2))) <= 1e-12  # end points and linearity
+
+
+def test_rccl_library_override_is_an_abi_call(tmp_path):
+    """crd_comm_set_rccl_library names the file the nccl* entry points are bound from at first use (another RCCL build; the multi-process
+    ring tests' stand-in).  No GPU needed to see the binding rule: a file that does not exist is reported by the first call that needs
+    RCCL, with the file's name, as CRD_ERCCL; NULL / "" selects librccl.so.1 again; the Python package applies CRD_RCCL_LIBRARY."""
+    import subprocess
+    import sys
+
+    code = (
+        "import ctypes as C, crdmodel_amd as crd\n"
+        "L = crd._capi.lib()\n"
+        "buf = C.create_string_buffer(128)\n"
+        "assert L.crd_comm_set_rccl_library(b'/nonexistent/librccl_other.so') == 0\n"
+        "rc = L.crd_comm_unique_id(buf)\n"
+        "print(rc, L.crd_last_error(None).decode())\n"
+        "assert L.crd_comm_set_rccl_library(None) == 0 and L.crd_comm_set_rccl_library(b'') == 0\n"
+    )
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=ROOT, timeout=120)
+    assert r.returncode == 0, r.stderr
+    rc, message = r.stdout.strip().split(" ", 1)
+    assert int(rc) == crd._capi.ERCCL and "/nonexistent/librccl_other.so" in message
+    # ... and through the environment of a Python process
+    r = subprocess.run([sys.executable, "-c", "import crdmodel_amd as crd\ntry:\n    crd.rccl_unique_id()\nexcept Exception as e:\n    print(e)\n"], capture_output=True, text=True,
+                       cwd=ROOT, timeout=120, env=dict(os.environ, CRD_RCCL_LIBRARY="/nonexistent/from_env.so"))
+    assert r.returncode == 0 and "/nonexistent/from_env.so" in r.stdout, (r.stdout, r.stderr)
