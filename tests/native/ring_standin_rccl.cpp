@@ -187,6 +187,7 @@ ncclResult_t ncclGetUniqueId(ncclUniqueId *id)
 ncclResult_t ncclCommInitRank(ncclComm_t *comm, int nranks, ncclUniqueId id, int rank)
 {
 	if (!comm || nranks < 1 || nranks > kMaxRanks || rank < 0 || rank >= nranks || id.internal[0] != '/') return failed("bad argument to ncclCommInitRank");
+	if (std::getenv("CRD_STANDIN_FAIL_INIT")) return failed("ncclCommInitRank fails on request (CRD_STANDIN_FAIL_INIT)");  // a ring that does not come up
 	ncclComm *c = new ncclComm;
 	c->rank = rank;
 	c->n = nranks;

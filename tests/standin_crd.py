@@ -58,6 +58,10 @@ class Slab:
         assert bytes(ident) == rccl_unique_id(), "the id every rank joins with is rank 0's"
         if os.environ.get("STANDIN_FAIL_RING"):  # (a ring that does not come up: bench.py --transport auto then runs the LOCAL leg)
             raise RuntimeError("stand-in: ncclCommInitRank failed")
+        if os.environ.get("STANDIN_HANG_RING") and self.slab == int(os.environ["STANDIN_HANG_RING"]):  # (... or hangs at first contact, on that rank)
+            import time
+
+            time.sleep(3600)
         self.ring = True
 
     def set_stepper(self, stepper):

@@ -307,3 +307,49 @@ def test_bench_falls_back_to_the_local_transport_and_runs_it_on_request():
     d = json.loads(r.stdout.strip().splitlines()[-1])
     assert d["config"]["halo"]["transport"] == "local" and d["config"]["launcher"]["transports_tried"] == ["rccl", "local"]
     assert d["config"]["launcher"]["fallback_reasons"] and d["config"]["launcher"]["fallback_reasons"][0].startswith("rccl: rank exit codes")
+
+
+def _run_ranks_like_torchrun(world, argv, extra_env, timeout=240):
+    """`world` processes of bench.py with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set by the caller, as torch.distributed.run starts them
+    (the form the driver uses for N > 1).  Returns [(returncode, stdout, stderr)] by rank."""
+    import subprocess
+
+    base = dict(os.environ, PYTHONPATH=ROOT + os.pathsep + os.environ.get("PYTHONPATH", ""), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                MASTER_PORT=str(_free_port()), **extra_env)
+    base.pop("CRD_BENCH_SELF_LAUNCHED", None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE,
+                              stderr=subprocess.PIPE, text=True) for r in range(world)]
+    out = []
+    for pr in procs:
+        try:
+            o, e = pr.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        out.append((pr.returncode, o, e))
+    return out
+
+
+@pytest.mark.parametrize("failure", ["error", "hang"])
+def test_ranks_started_by_an_external_launcher_fall_back_too(failure):
+    """The driver starts N > 1 as `python -m torch.distributed.run ... bench.py --gpus N`: no launcher of ours is there to run the LOCAL leg
+    when the ring fails at first contact.  The ranks then settle it among themselves: every rank reports how its bring-up went over the
+    control plane (a rank stuck inside communicator set-up stops WAITING for it after --ring-timeout-s), ranks 1.. leave with status
+    0, rank 0 runs the LOCAL leg in a child process and passes its line on, saying what happened -- the run still yields a number.
+    With --transport rccl (asked for by name) the ranks leave with status 4 instead."""
+    common = ["--gpus", "2", "--size", "64", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--crd-module", "tests.standin_crd", "--preheat-ms", "0",
+              "--ring-timeout-s", "3"]
+    env = {"STANDIN_FAIL_RING": "1"} if failure == "error" else {"STANDIN_HANG_RING": "1"}
+    res = _run_ranks_like_torchrun(2, common, env)
+    assert [r[0] for r in res] == [0, 0], [(r[0], r[2][-1500:]) for r in res]
+    lines = [ln for ln in res[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not res[1][1].strip()
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["halo"]["transport"] == "local" and d["value"] > 0
+    la = d["config"]["launcher"]
+    assert la["transports_tried"] == ["rccl", "local"] and "external launcher" in la["mode"]
+    assert ("ncclCommInitRank failed" if failure == "error" else "did not come up within 3 s") in la["fallback_reasons"][0]
+    # asked for by name: no fallback, status 4 on every rank
+    res = _run_ranks_like_torchrun(2, common + ["--transport", "rccl"], env)
+    assert [r[0] for r in res] == [4, 4] and not any(ln.startswith("{") for ln in res[0][1].splitlines())

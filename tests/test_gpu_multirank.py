@@ -188,3 +188,36 @@ def test_bench_with_rank_processes_on_one_gpu(gpu_device, standin, world):
     assert halo["halo_selfcheck"]["ok"] and halo["halo_selfcheck"]["mismatching_values"] == 0
     assert d["config"]["decomposition"] == "phi-slabs x%d" % world and len(d["per_rank"]) == world
     assert d["config"]["launcher"]["transports_tried"] == ["rccl"]
+
+
+def test_ranks_under_an_external_launcher_fall_back_to_the_local_leg(gpu_device, standin):
+    """Two rank processes of bench.py started the way torch.distributed.run starts them (RANK / WORLD_SIZE / MASTER_* set by the caller),
+    with a ring that does not come up (the stand-in's ncclCommInitRank fails on request): the ranks settle it over the control plane,
+    rank 1 leaves with status 0, rank 0 runs the LOCAL leg (both slabs on the box's one GPU: --devices 0,0) in a child process and
+    passes its line on with the reason -- the shipped library and kernels throughout."""
+    import socket
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    base = dict(os.environ, CRD_RCCL_LIBRARY=standin, CRD_STANDIN_FAIL_INIT="1", WORLD_SIZE="2", LOCAL_WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    base.pop("CRD_BENCH_SELF_LAUNCHED", None)
+    argv = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--devices", "0,0", "--size", "2048", "--steps", "24", "--warmup", "6", "--repeats", "1",
+            "--no-cpu-baseline"]
+    procs = [subprocess.Popen(argv, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    res = []
+    for pr in procs:
+        try:
+            o, e = pr.communicate(timeout=400)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        res.append((pr.returncode, o, e))
+    assert [r[0] for r in res] == [0, 0], [(r[0], r[2][-2000:]) for r in res]
+    lines = [ln for ln in res[0][1].splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and not res[1][1].strip()
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["config"]["halo"]["transport"] == "local" and d["config"]["halo"]["devices"] == [0, 0]
+    la = d["config"]["launcher"]
+    assert la["transports_tried"] == ["rccl", "local"] and "external launcher" in la["mode"] and "CRD_STANDIN_FAIL_INIT" in la["fallback_reasons"][0]
