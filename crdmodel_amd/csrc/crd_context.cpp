@@ -241,17 +241,20 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	build_beta_rows(c->p, c->g, c->js - kGhost, c->je + 1 + kGhost, &brow);
 	if (p->model == CRD_MODEL_GOLDBETER)  // the kernels take the row-constant source term v0 + v1 b(j) of src/GoldbeterModel_torus.cpp:715 ready-made
 		for (double &b : brow) b = std::fma(kGbV1, b, kGbV0);
+	else  // FHN: EPSILON b(j), the addend of dv = fma(EPSILON, u, EPSILON b) (src/FHNmodel_torus.cpp:660)
+		for (double &b : brow) b = kFhnEpsilon * b;
 	if (d0 > 1) {  // the block's own columns of the per-column tables
-		co.cA = std::vector<double>(co.cA.begin() + c->is, co.cA.begin() + c->ie + 1);
+		co.cE = std::vector<double>(co.cE.begin() + c->is, co.cE.begin() + c->ie + 1);
+		co.cWn = std::vector<double>(co.cWn.begin() + c->is, co.cWn.begin() + c->ie + 1);
 		co.cP = std::vector<double>(co.cP.begin() + c->is, co.cP.begin() + c->ie + 1);
 	}
-	if ((rc = upload_table(c, co.cA, &c->cA)) || (rc = upload_table(c, co.cP, &c->cP)) || (rc = upload_table(c, brow, &c->brow))) return bail(rc);
+	if ((rc = upload_table(c, co.cE, &c->cE)) || (rc = upload_table(c, co.cWn, &c->cWn)) || (rc = upload_table(c, co.cP, &c->cP)) || (rc = upload_table(c, brow, &c->brow))) return bail(rc);
 
 	SlabDesc &d = c->desc;
-	d.cA = c->cA;
+	d.cE = c->cE;
+	d.cWn = c->cWn;
 	d.cP = c->cP;
 	d.brow = c->brow;
-	d.cX = co.cX;
 	d.ka4 = std::pow(kGbKa, 4.0);  // pow(KA, p), src/GoldbeterModel_torus.cpp:695
 	d.nx = c->nx;
 	d.nyl = c->nyl;
@@ -278,7 +281,7 @@ void crd_destroy(crd_ctx *c)
 	if (c->nccl && g_rccl.handle) (void)g_rccl.CommDestroy(c->nccl);
 	for (void *q : c->plane_allocs) (void)hipFree(q);
 	if (c->scalar_host) (void)hipHostFree(c->scalar_host);
-	for (void *q : {c->cA, c->cP, c->brow, c->stage_in, c->stage_out, c->ghost_lo, c->ghost_hi, c->edge_lo, c->edge_hi, (void *)c->scalar_dev,
+	for (void *q : {c->cE, c->cWn, c->cP, c->brow, c->stage_in, c->stage_out, c->ghost_lo, c->ghost_hi, c->edge_lo, c->edge_hi, (void *)c->scalar_dev,
 	                (void *)c->err_partials, c->ghost_col[0], c->ghost_col[1], c->edge_col[0], c->edge_col[1]})
 		if (q) (void)hipFree(q);
 	for (auto &pl : c->gcol)

@@ -112,7 +112,7 @@ struct crd_ctx {
 	void *plane[NPLANES][2] = {};
 	std::vector<void *> plane_allocs;  // what hipMalloc returned for them (a plane starts `plane_skew` x its index into its allocation)
 	size_t plane_skew = 0;             // bytes; see alloc_plane (crd_context.cpp)
-	void *cA = nullptr, *cP = nullptr, *brow = nullptr;
+	void *cE = nullptr, *cWn = nullptr, *cP = nullptr, *brow = nullptr;
 	void *stage_in = nullptr, *stage_out = nullptr;  // AoS staging for the *_host entry points (lazy)
 	size_t stage_bytes = 0;
 	void *ghost_lo = nullptr, *ghost_hi = nullptr;   // var0 of rows -1 / nyl for the AoS RHS (multi-slab)

@@ -24,8 +24,8 @@ template <> struct Pair<float> { using type = float2; };
 
 template <typename Real>
 struct Slab {
-	const Real *cA, *cP, *brow;
-	Real cX, ka4;
+	const Real *cE, *cWn, *cP, *brow;
+	Real ka4;
 	int nx, nyl, wrap, has_row0, has_rowN, just_diffusion, wrap_x;
 };
 
@@ -33,10 +33,10 @@ template <typename Real>
 inline Slab<Real> typed(const SlabDesc &d)
 {
 	Slab<Real> s;
-	s.cA = static_cast<const Real *>(d.cA);
+	s.cE = static_cast<const Real *>(d.cE);
+	s.cWn = static_cast<const Real *>(d.cWn);
 	s.cP = static_cast<const Real *>(d.cP);
 	s.brow = static_cast<const Real *>(d.brow) + kGhost;  // index by local row
-	s.cX = (Real)d.cX;
 	s.ka4 = (Real)d.ka4;
 	s.nx = d.nx;
 	s.nyl = d.nyl;
@@ -56,7 +56,7 @@ inline Real *row0(void *plane, int nx)
 }
 
 // The point function: diffusion + kinetics of one grid point.
-//   diffusion  src/FHNmodel_torus.cpp:535-537 with the theta-only factors folded into cA / cX / cP
+//   diffusion  src/FHNmodel_torus.cpp:535-537 with the theta-only factors folded into the tables cE / cWn / cP
 //   FHN        src/FHNmodel_torus.cpp:657,660
 //   Goldbeter  src/GoldbeterModel_torus.cpp:694-695,715-716 (pow(x,2), pow(x,4) as multiplies)
 //   absorbing  src/FHNmodel_torus.cpp:643-653 (zero = row is a global phi boundary row and t < TBOUNDARY)
@@ -133,41 +133,57 @@ __device__ __forceinline__ double2v reciprocal(double2v x)
 constexpr int kModelDiffusionOnly = 2;
 inline int kernel_model(const SlabDesc &d) { return (d.model == CRD_MODEL_GOLDBETER && d.just_diffusion) ? kModelDiffusionOnly : d.model; }
 
-// rowp is the per-row parameter of the kinetics: FHN b(j) (src/FHNmodel_torus.cpp:623-632); Goldbeter v0 + v1 b(j), the
-// row-constant source term of src/GoldbeterModel_torus.cpp:715, formed once on the host (crd_create).
-// V: the lane's value type -- a Real, or two of them (two columns per lane); cX, rowp, ka4 are the same for both columns.
+// rowp is the per-row parameter of the kinetics, formed once on the host (crd_create): FHN EPSILON b(j) (src/FHNmodel_torus.cpp:623-632,
+// 660); Goldbeter v0 + v1 b(j), the row-constant source term of src/GoldbeterModel_torus.cpp:715.
+// V: the lane's value type -- a Real, or two of them (two columns per lane); rowp, ka4 are the same for both columns.
+//
+// Round 5: the theta part of the operator works on FIRST differences.  With gE = uE - uC, gW = uC - uW,
+//   cA (uE - uW) + cX (uE - 2 uC + uW)  =  (cX + cA) gE - (cX - cA) gW  =  cE gE + cWn gW
+// (cE = cX + cA and cWn = cA - cX are tables, build_coefficients): two fused multiply-adds on one difference per point -- the
+// neighbour's gE IS this point's gW, so the one-launch steppers form one difference per point and fetch the other with the lane
+// shift they need anyway -- where round 4 spent five instructions (uE - uW, two for the second difference, two multiply-adds).
+// Like the second difference, a first difference of neighbouring values is exact or correct to half an ulp of u, and a uniform
+// field still diffuses to exactly zero (gE = gW = 0, d2y = 0).  The reaction terms ride the same chain: FHN's "- v" is the
+// chain's first addend, 3 u - u^3 = u (3 - u^2) is two multiply-adds, EPSILON (u + b) one with EPSILON b(j) as the row parameter:
+// 9 arithmetic instructions per FHN point (round 4: 15), Goldbeter 26 (31) -- these kernels are bound by vector issue.
 template <typename V, int MODEL>
-__device__ __forceinline__ void rhs_point(V uC, V uW, V uE, V uS, V uN, V v, V cA, typename ScalarOf<V>::type cX, V cP, typename ScalarOf<V>::type rowp,
+__device__ __forceinline__ void rhs_point(V uC, V gW, V gE, V uS, V uN, V v, V cE, V cWn, V cP, typename ScalarOf<V>::type rowp,
                                           typename ScalarOf<V>::type ka4, bool zero, V &du, V &dv)
 {
-	// second differences as the reference writes them, (uE - 2 uC + uW), so that a constant field diffuses to exactly zero
-	const V d2x = fmadd(splat<V>(-2.0), uC, uE) + uW;
+	// the phi second difference as the reference writes it, (uN - 2 uC + uS)
 	const V d2y = fmadd(splat<V>(-2.0), uC, uN) + uS;
-	const V diff = fmadd(cA, uE - uW, fmadd((V)cX, d2x, cP * d2y));
 	if (MODEL == kModelDiffusionOnly) {
-		du = diff;
+		du = fmadd(cWn, gW, fmadd(cE, gE, cP * d2y));
 		dv = splat<V>(0.0);
 		return;
 	} else if (MODEL == CRD_MODEL_FHN) {
-		const V u3 = (uC * uC) * uC;
-		du = diff + (fmadd(splat<V>(3.0), uC, -u3) - v);
-		dv = splat<V>(kFhnEpsilon) * (uC + (V)rowp);
+		const V r = fmadd(cWn, gW, fmadd(cE, gE, fmadd(cP, d2y, -v)));  // diffusion - v
+		du = fmadd(uC, fmadd(-uC, uC, splat<V>(3.0)), r);               // + u (3 - u^2)
+		dv = fmadd(splat<V>(kFhnEpsilon), uC, (V)rowp);                 // rowp = EPSILON b
 	} else {
 		// v2 = VM2 z^2 / (K2^2 + z^2), v3 = VM3 y^2 z^4 / ((KR^2 + y^2)(KA^4 + z^4)) enter both equations only through
 		// w = v2 - v3 (src/GoldbeterModel_torus.cpp:715-716: dZ = v0 + v1 b - w + kf Y - k Z, dY = w - kf Y): one quotient
-		// w = (VM2 z^2 dB - VM3 y^2 z^4 dA) / (dA dB) with dA = K2^2 + z^2, dB = (KR^2 + y^2)(KA^4 + z^4) -- 23 instructions for
-		// the kinetics against 27 with the two Hill terms formed separately (this kernel is bound by fp64 issue).
+		// w = (VM2 z^2 dB - VM3 y^2 z^4 dA) / (dA dB) with dA = K2^2 + z^2, dB = (KR^2 + y^2)(KA^4 + z^4).
 		const V z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
-		const V dA = splat<V>(kGbK2 * kGbK2) + z2, dB = (splat<V>(kGbKr * kGbKr) + y2) * ((V)ka4 + z4);
-		const V n2 = (splat<V>(kGbVm2) * z2) * dB, n3 = ((splat<V>(kGbVm3) * y2) * z4) * dA;
-		const V w = (n2 - n3) * reciprocal(dA * dB);
-		dv = w - splat<V>(kGbKf) * v;
-		du = diff + fmadd(-splat<V>(kGbK), uC, (V)rowp - dv);  // rowp = v0 + v1 b
+		const V dA = splat<V>(kGbK2 * kGbK2) + z2, dB = (splat<V>(kGbKr * kGbKr) + y2) * fmadd(z2, z2, (V)ka4);
+		const V n3 = splat<V>(kGbVm3) * ((y2 * z4) * dA);
+		const V w = fmadd(splat<V>(kGbVm2), z2 * dB, -n3) * reciprocal(dA * dB);
+		dv = fmadd(splat<V>(-kGbKf), v, w);
+		const V r = fmadd(splat<V>(-kGbK), uC, (V)rowp - dv);  // rowp = v0 + v1 b
+		du = fmadd(cWn, gW, fmadd(cE, gE, fmadd(cP, d2y, r)));
 	}
 	if (zero) {
 		du = splat<V>(0.0);
 		dv = splat<V>(0.0);
 	}
+}
+
+// ... from the neighbour VALUES (the tiled kernels, which have them in LDS): the same differences, the same bits.
+template <typename V, int MODEL>
+__device__ __forceinline__ void rhs_point_values(V uC, V uW, V uE, V uS, V uN, V v, V cE, V cWn, V cP, typename ScalarOf<V>::type rowp,
+                                                 typename ScalarOf<V>::type ka4, bool zero, V &du, V &dv)
+{
+	rhs_point<V, MODEL>(uC, uC - uW, uE - uC, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
 }
 
 // blockIdx -> tile id.  Workgroups are dealt round-robin over the 8 XCDs (each with a private L2), so tile ids that

@@ -111,6 +111,17 @@ __device__ __forceinline__ float2v from_lane_above(float2v v) { return pair_from
 __device__ __forceinline__ double2v from_lane_below(double2v v) { return pair_from_below(v); }
 __device__ __forceinline__ double2v from_lane_above(double2v v) { return pair_from_above(v); }
 
+// The point function on a lane of the marching wavefront: the theta neighbours are the adjacent lanes.  ONE first difference per
+// point, gE = u(lane + 1) - u(lane); the other one, gW = u(lane) - u(lane - 1), is the gE of the lane below, fetched with the second
+// shift (crd_device.h: rhs_point).  Edge lanes get apron garbage by design.
+template <typename V, int MODEL>
+__device__ __forceinline__ void rhs_lane(V uC, V uS, V uN, V v, V cE, V cWn, V cP, typename ScalarOf<V>::type rowp, typename ScalarOf<V>::type ka4, bool zero,
+                                         V &du, V &dv)
+{
+	const V gE = from_lane_above(uC) - uC;
+	rhs_point<V, MODEL>(uC, from_lane_below(gE), gE, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
+}
+
 // f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a compile-time unrolled loop.
 template <typename F, int... Is>
 __device__ __forceinline__ void for_sequence(F &&f, std::integer_sequence<int, Is...>)
@@ -237,7 +248,7 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 	if (x < 0) x += nx;
 	// lane offsets in bytes, unsigned 32-bit: with a scalar row base the accesses take the `global_load v, v_off, s[base]` form and
 	// no 64-bit vector add is spent per access
-	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real), ob = (unsigned)(strip * VALID + (COLS * lane - APRON)) * (unsigned)sizeof(Real);
+	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real);  // (a lane that stores has x == out_col: its column is inside [0, nx) unwrapped, so xb serves the stores too)
 	const int out_col = strip * VALID + (COLS * lane - APRON);
 	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;  // (two columns: nx is even, so is out_col)
 
@@ -249,8 +260,8 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 	const int niter = (j1 - j0) + 2 * APRON;
 	const int jlast = j1 + APRON - 1;  // last row the pipeline consumes
 
-	const V cA = *reinterpret_cast<const V *>(s.cA + x), cP = *reinterpret_cast<const V *>(s.cP + x);
-	const Real cX = s.cX, ka4 = s.ka4;
+	const V cE = *reinterpret_cast<const V *>(s.cE + x), cWn = *reinterpret_cast<const V *>(s.cWn + x), cP = *reinterpret_cast<const V *>(s.cP + x);
+	const Real ka4 = s.ka4;
 	const V h1 = (V)a.h1, h2 = (V)a.h2, h3 = (V)a.h3, h6 = (V)a.h6;
 	// b(j) is read-only for the whole launch and its index is uniform: through the constant address space the reads become
 	// scalar-cache loads into SGPRs (s_load_dwordx2), no vector registers and no vector-memory instruction
@@ -347,7 +358,7 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 		// ---- stage 1, centre row p-1: y0 rows p-2, p-1, p -----------------------------------------------------
 		if (!GUARDED || m >= 2) {
 			const int c = p - 1;
-			rhs_point<V, MODEL>(u0[S1], from_lane_below(u0[S1]), from_lane_above(u0[S1]), u0[S2], u0[S0], v0[S1], cA, cX, cP, bq[S1], ka4,
+			rhs_lane<V, MODEL>(u0[S1], u0[S2], u0[S0], v0[S1], cE, cWn, cP, bq[S1], ka4,
 			                       ABSORB && a.absorb[0] && boundary_row(c), du, dv);
 			U1[S1] = fmadd(h2, du, u0[S1]);
 			V1[A1] = fmadd(h2, dv, v0[S1]);
@@ -359,7 +370,7 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 		// ---- stage 2, centre row p-2: y1 rows p-3, p-2, p-1 ---------------------------------------------------
 		if (!GUARDED || m >= 4) {
 			const int c = p - 2;
-			rhs_point<V, MODEL>(U1[S2], from_lane_below(U1[S2]), from_lane_above(U1[S2]), U1[S3], U1[S1], V1[A2], cA, cX, cP, bq[S2], ka4,
+			rhs_lane<V, MODEL>(U1[S2], U1[S3], U1[S1], V1[A2], cE, cWn, cP, bq[S2], ka4,
 			                       ABSORB && a.absorb[1] && boundary_row(c), du, dv);
 			U2[S2] = fmadd(h2, du, u0[S2]);
 			V2[B2] = fmadd(h2, dv, v0[S2]);
@@ -371,7 +382,7 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 		// ---- stage 3, centre row p-3: y2 rows p-4, p-3, p-2 ---------------------------------------------------
 		if (!GUARDED || m >= 6) {
 			const int c = p - 3;
-			rhs_point<V, MODEL>(U2[S3], from_lane_below(U2[S3]), from_lane_above(U2[S3]), U2[S4], U2[S2], V2[B3], cA, cX, cP, bq[S3], ka4,
+			rhs_lane<V, MODEL>(U2[S3], U2[S4], U2[S2], V2[B3], cE, cWn, cP, bq[S3], ka4,
 			                       ABSORB && a.absorb[2] && boundary_row(c), du, dv);
 			U3[S3] = fmadd(h1, du, u0[S3]);
 			V3[S3 & 1] = fmadd(h1, dv, v0[S3]);
@@ -383,7 +394,7 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 		// ---- stage 4, centre row p-4: y3 rows p-5, p-4, p-3 -> the new state ----------------------------------
 		if (!GUARDED || m >= 8) {
 			const int c = p - 4;
-			rhs_point<V, MODEL>(U3[S4], from_lane_below(U3[S4]), from_lane_above(U3[S4]), U3[S5], U3[S3], V3[S4 & 1], cA, cX, cP, b4, ka4,
+			rhs_lane<V, MODEL>(U3[S4], U3[S5], U3[S3], V3[S4 & 1], cE, cWn, cP, b4, ka4,
 			                       ABSORB && a.absorb[3] && boundary_row(c), du, dv);
 			V nu, nv;
 			if (ZONN) {
@@ -404,8 +415,8 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 			// Without the fifth stage rows j0 <= c < j1 are exactly iterations 8 .. niter-1; with it (one more apron row each side)
 			// the first and the last iteration of the range fall outside.
 			if ((EMBED == 0 || (c >= j0 && c < j1)) && lane_stores) {
-				row_store<NT>(at_lane_as<V>(out_row_u, ob), nu);
-				row_store<NT>(at_lane_as<V>(out_row_v, ob), nv);
+				row_store<NT>(at_lane_as<V>(out_row_u, xb), nu);
+				row_store<NT>(at_lane_as<V>(out_row_v, xb), nv);
 			}
 			if (EMBED == 1) {
 				U4[S4] = nu;
@@ -417,7 +428,7 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 		// ---- stage 5 (EMBED), centre row p-5: y_new rows p-6, p-5, p-4 -> k5 and the error of row p-5 ----------
 		if (EMBED != 0 && (!GUARDED || m >= 10)) {
 			const int c = p - 5;
-			rhs_point<V, MODEL>(U4[Z5], from_lane_below(U4[Z5]), from_lane_above(U4[Z5]), U4[Z6], U4[Z4], V4[S5 & 1], cA, cX, cP, bq[S5], ka4,
+			rhs_lane<V, MODEL>(U4[Z5], U4[Z6], U4[Z4], V4[S5 & 1], cE, cWn, cP, bq[S5], ka4,
 			                       ABSORB && a.absorb[4] && boundary_row(c), du, dv);  // k5 at t + dt like k4 (EMBED 1) or at t + 3/4 dt (Zonneveld)
 			if (lane_stores && c >= a.err_lo && c < a.err_hi) {  // rows j0 .. j1-1 exactly (stage 5 starts at iteration 10, row j0, and the loop ends at row j1-1), owned rows only
 				const V au = __builtin_elementwise_abs(u0[S5]), av = __builtin_elementwise_abs(v0[S5]);
@@ -463,6 +474,57 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 	}
 }
 
+// ---- the two-step pipeline's memory path (round 5) ----------------------------------------------------------------------------
+// Rows enter through LDS, fetched by LDS-DMA (buffer_load_dword ... lds) kRingRows iterations ahead of their use: the data of a
+// load in flight needs no vector register, so the depth of the prefetch is a matter of LDS (a wavefront's ring: kRingRows x
+// 1 KiB in fp64), not of the 168-register line the pipeline sits at.  (Round 4 held two rows per field in registers; under the
+// counter's in-order rule -- vmcnt counts loads and stores together -- the wait in front of a row's first use also waited for
+// the previous iteration's stores and loads: a wavefront took 2400 cycles per iteration of which it issued 590, and three
+// wavefronts per SIMD could not cover that.)  A buffer resource per row (scalar base) + a lane offset: no 64-bit vector
+// address arithmetic, and the stores take the same form.
+#ifndef CRD_RING_ROWS
+#define CRD_RING_ROWS 4
+#endif
+constexpr int kRingRowsWanted = CRD_RING_ROWS;  // a multiple of the unroll factor 4; rows in flight per wavefront
+// ... as far as the six bits of vmcnt allow (a row of 1 KiB per field takes eight LDS-DMA instructions)
+template <typename V>
+constexpr int kRingRowsOf = (kLanes * (int)sizeof(V) / 256 >= 4 && kRingRowsWanted > 4) ? 4 : kRingRowsWanted;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t row_resource(const void *row)
+{
+	// raw buffer (stride 0) over the bytes from `row` on: offsets are a lane's byte offset within its row (< 2 GiB)
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(row), 0, 0x7fffffff, 0x00020000);
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void buffer_row_store(__amdgpu_buffer_rsrc_t r, unsigned byte_offset, V v)
+{
+	constexpr int aux = NT ? 2 : 0;  // (2 = nt)
+	if constexpr (sizeof(V) == 4) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, byte_offset, 0, aux);
+	else if constexpr (sizeof(V) == 8) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), r, byte_offset, 0, aux);
+	else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_offset, 0, aux);
+}
+// Both fields of a ring slot into registers: waits until at most VMCNT vector-memory operations of this wavefront are outstanding
+// (the slot's LDS-DMA has landed then: the counter retires in issue order), reads, waits for the reads.  One asm statement, so no
+// instruction of the compiler's can come between a read and its wait.
+template <int VMCNT, int OFF_U, int OFF_V, typename V>
+__device__ __forceinline__ void ring_read(unsigned lds_lane, V &u, V &v)
+{
+	if constexpr (sizeof(V) == 4)
+		asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b32 %0, %2 offset:%4\n\tds_read_b32 %1, %2 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+		             : "=&v"(u), "=&v"(v) : "v"(lds_lane), "n"(VMCNT), "n"(OFF_U), "n"(OFF_V) : "memory");
+	else if constexpr (sizeof(V) == 8)
+		asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b64 %0, %2 offset:%4\n\tds_read_b64 %1, %2 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+		             : "=&v"(u), "=&v"(v) : "v"(lds_lane), "n"(VMCNT), "n"(OFF_U), "n"(OFF_V) : "memory");
+	else
+		asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %2 offset:%5\n\ts_waitcnt lgkmcnt(0)"
+		             : "=&v"(u), "=&v"(v) : "v"(lds_lane), "n"(VMCNT), "n"(OFF_U), "n"(OFF_V) : "memory");
+}
+// LDS bytes of a block's rings
+template <typename Real, int COLS>
+constexpr int kRingBytes = kMaxWavesPerBlock * kRingRowsOf<typename LaneValue<Real, COLS>::type> * 2 * kLanes * COLS * (int)sizeof(Real);
+
 // TWO classical RK4 steps of the item's rows in one pass over memory (STEPS = 2; round 4): the pipeline of fused_item twice over,
 // eight stages deep -- iteration m takes row p from memory, runs stages 1..4 of step n on rows p-1 .. p-4, hands the new row p-4
 // to a second, identical pipeline as ITS input row, which runs stages 1..4 of step n+1 on rows p-5 .. p-8 and stores row p-8.
@@ -482,21 +544,27 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 // i.e. the SAME slots -- the stage code is one lambda applied to two sets of arrays.  Per point the arithmetic is the sequence of
 // two single steps exactly (same fused multiply-adds, same constants), so the result is theirs bit for bit.
 template <typename Real, int MODEL, bool ABSORB, int COLS, bool NT>
-__device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk)
+__device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk, lds_char *const block_rings)
 {
 	using V = typename LaneValue<Real, COLS>::type;
 	constexpr int APRON = 2 * kApron;
 	static_assert(APRON % COLS == 0, "the apron is whole lanes");
 	constexpr int VALID = COLS * kLanes - 2 * APRON;
 	constexpr int M = 4;
-	constexpr int kPrefetch = CRD_PREFETCH_TWO;
-	static_assert(M % kPrefetch == 0, "prefetch slots are addressed with the unrolled iteration index");
+	// the ring: kRingRows slots of [u row segment | v row segment], RB bytes each, filled 256 B (64 lanes x one dword) per LDS-DMA
+	constexpr int RB = kLanes * (int)sizeof(V), SLOT = 2 * RB, G1 = RB / 256, kRingRows = kRingRowsOf<V>;
+	static_assert(kRingRows % M == 0 && kRingRows >= M && (kRingRows & (kRingRows - 1)) == 0, "ring slots are addressed with the unrolled iteration index");
+	// vector-memory operations a wavefront issues per iteration: 2 G1 LDS-DMA loads, and 2 stores once rows come out.  When the slot
+	// of iteration m is read, the operations issued after its fill (at iteration m - kRingRows) are the fills of kRingRows - 1
+	// iterations and the stores of kRingRows iterations -- none of the latter while the pipeline still fills.
+	constexpr int kWaitFill = (kRingRows - 1) * 2 * G1, kWaitSteady = kWaitFill + 2 * kRingRows;
+	static_assert(kWaitSteady <= 63, "vmcnt is six bits");
 	const int lane = threadIdx.x & (kLanes - 1);
 	const int nx = s.nx;
 	int x = strip * VALID - APRON + COLS * lane;
 	x %= nx;
 	if (x < 0) x += nx;
-	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real), ob = (unsigned)(strip * VALID + (COLS * lane - APRON)) * (unsigned)sizeof(Real);
+	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real);  // (a lane that stores has x == out_col: its column is inside [0, nx) unwrapped, so xb serves the stores too)
 	const int out_col = strip * VALID + (COLS * lane - APRON);
 	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;
 
@@ -508,8 +576,8 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	const int niter = (j1 - j0) + 2 * APRON;
 	const int jlast = j1 + APRON - 1;
 
-	const V cA = *reinterpret_cast<const V *>(s.cA + x), cP = *reinterpret_cast<const V *>(s.cP + x);
-	const Real cX = s.cX, ka4 = s.ka4;
+	const V cE = *reinterpret_cast<const V *>(s.cE + x), cWn = *reinterpret_cast<const V *>(s.cWn + x), cP = *reinterpret_cast<const V *>(s.cP + x);
+	const Real ka4 = s.ka4;
 	const V h1 = (V)a.h1, h2 = (V)a.h2, h3 = (V)a.h3, h6 = (V)a.h6;
 	const __attribute__((address_space(4))) Real *const brow = (const __attribute__((address_space(4))) Real *)(s.brow);
 	const int wrap_nyl = s.wrap ? s.nyl : 0;
@@ -551,17 +619,33 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	A.V1[0] = A.V1[1] = A.V2[0] = A.V2[1] = A.V3[0] = A.V3[1] = zero_v;
 	B.V1[0] = B.V1[1] = B.V2[0] = B.V2[1] = B.V3[0] = B.V3[1] = zero_v;
 
-	V pu[kPrefetch], pv[kPrefetch];
-	Real pb[kPrefetch];
+	// This wavefront's ring, and where its lanes read: lane l takes the l-th value (of sizeof(V) bytes) of a row segment.
+	lds_char *const ring = block_rings + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (kRingRows * SLOT);
+	const unsigned ring_lane = (unsigned)(uintptr_t)ring + (unsigned)lane * (unsigned)sizeof(V);
+	// ... and what they fetch: LDS-DMA instruction h of a row moves dwords 64 h + lane of the segment; the column of a dword's
+	// element wraps periodically like x above
+	unsigned doff[G1];
 #pragma unroll
-	for (int k = 0; k < kPrefetch; k++) {
-		const int jr = (jbase + k < jlast) ? jbase + k : jlast;
-		const ptrdiff_t rb = row_base(jr);
-		pu[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
-		pv[k] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
-		pb[k] = brow[jr];
+	for (int h = 0; h < G1; h++) {
+		const int q = 4 * (kLanes * h + lane), e = q / (int)sizeof(Real);
+		int col = (strip * VALID - APRON + e) % nx;
+		if (col < 0) col += nx;
+		doff[h] = (unsigned)col * (unsigned)sizeof(Real) + (unsigned)(q % (int)sizeof(Real));
 	}
-	int jn = (jbase + kPrefetch < jlast) ? jbase + kPrefetch : jlast;
+	auto fill = [&](int jrow, int slot_byte) {  // row jrow of both fields -> the ring slot at byte `slot_byte` (uniform)
+		const ptrdiff_t rb = row_base(jrow);
+		const __amdgpu_buffer_rsrc_t ru = row_resource(a.in_u + rb), rv = row_resource(a.in_v + rb);
+#pragma unroll
+		for (int h = 0; h < G1; h++) __builtin_amdgcn_raw_ptr_buffer_load_lds(ru, ring + (slot_byte + 256 * h), 4, doff[h], 0, 0, 0);
+#pragma unroll
+		for (int h = 0; h < G1; h++) __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, ring + (slot_byte + RB + 256 * h), 4, doff[h], 0, 0, 0);
+	};
+#pragma unroll
+	for (int k = 0; k < kRingRows; k++) fill((jbase + k < jlast) ? jbase + k : jlast, k * SLOT);
+	int jn = (jbase + kRingRows < jlast) ? jbase + kRingRows : jlast;  // the row the next fill takes (the tail re-reads the last valid row)
+	Real pb = brow[jbase];                                            // b(j) of the row the next iteration takes
+	int trip_byte = 0;                                                // ring byte offset of the slots of this trip of four iterations
+	unsigned ring_trip = ring_lane;
 	Real *out_row_u = a.out_u + (ptrdiff_t)(jbase - 2 * kApron) * nx, *out_row_v = a.out_v + (ptrdiff_t)(jbase - 2 * kApron) * nx;
 
 	// Stages 1..4 of one step on the pipeline P whose newest row is `p` (slot S0): new state of row p - 4 in (nu, nv).
@@ -570,68 +654,91 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		constexpr int K = decltype(kk)::value;
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M, S5 = (K + 2 * M - 5) % M;
 		V du, dv;
-		rhs_point<V, MODEL>(P.u0[S1], from_lane_below(P.u0[S1]), from_lane_above(P.u0[S1]), P.u0[S2], P.u0[S0], P.v0[S1], cA, cX, cP, P.bq[S1], ka4,
+		rhs_lane<V, MODEL>(P.u0[S1], P.u0[S2], P.u0[S0], P.v0[S1], cE, cWn, cP, P.bq[S1], ka4,
 		                       ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), du, dv);
 		P.U1[S1] = fmadd(h2, du, P.u0[S1]);
 		P.V1[S1 & 1] = fmadd(h2, dv, P.v0[S1]);
 		P.aU[S1] = fmadd(h6, du, P.u0[S1]);
 		P.aV[S1] = fmadd(h6, dv, P.v0[S1]);
-		rhs_point<V, MODEL>(P.U1[S2], from_lane_below(P.U1[S2]), from_lane_above(P.U1[S2]), P.U1[S3], P.U1[S1], P.V1[S2 & 1], cA, cX, cP, P.bq[S2], ka4,
+		rhs_lane<V, MODEL>(P.U1[S2], P.U1[S3], P.U1[S1], P.V1[S2 & 1], cE, cWn, cP, P.bq[S2], ka4,
 		                       ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), du, dv);
 		P.U2[S2] = fmadd(h2, du, P.u0[S2]);
 		P.V2[S2 & 1] = fmadd(h2, dv, P.v0[S2]);
 		P.aU[S2] = fmadd(h3, du, P.aU[S2]);
 		P.aV[S2] = fmadd(h3, dv, P.aV[S2]);
-		rhs_point<V, MODEL>(P.U2[S3], from_lane_below(P.U2[S3]), from_lane_above(P.U2[S3]), P.U2[S4], P.U2[S2], P.V2[S3 & 1], cA, cX, cP, P.bq[S3], ka4,
+		rhs_lane<V, MODEL>(P.U2[S3], P.U2[S4], P.U2[S2], P.V2[S3 & 1], cE, cWn, cP, P.bq[S3], ka4,
 		                       ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), du, dv);
 		P.U3[S3] = fmadd(h1, du, P.u0[S3]);
 		P.V3[S3 & 1] = fmadd(h1, dv, P.v0[S3]);
 		P.aU[S3] = fmadd(h3, du, P.aU[S3]);
 		P.aV[S3] = fmadd(h3, dv, P.aV[S3]);
-		rhs_point<V, MODEL>(P.U3[S4], from_lane_below(P.U3[S4]), from_lane_above(P.U3[S4]), P.U3[S5], P.U3[S3], P.V3[S4 & 1], cA, cX, cP, b4, ka4,
+		rhs_lane<V, MODEL>(P.U3[S4], P.U3[S5], P.U3[S3], P.V3[S4 & 1], cE, cWn, cP, b4, ka4,
 		                       ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), du, dv);
 		nu = fmadd(h6, du, P.aU[S4]);
 		nv = fmadd(h6, dv, P.aV[S4]);
 	};
 	auto iteration = [&](int m, auto kk) {
 		constexpr int K = decltype(kk)::value;
-		constexpr int S0 = K % M, S4 = (K + 2 * M - 4) % M, P0 = K % kPrefetch;
+		constexpr int S0 = K % M, S4 = (K + 2 * M - 4) % M;
 #if !defined(CRD_NO_LOCKSTEP) && !defined(CRD_NO_LOCKSTEP_TWO)
 		__builtin_amdgcn_s_barrier();
 #endif
 		const int p = jbase + m;
 		const Real b4a = A.bq[S4], b4b = B.bq[S4];
-		A.u0[S0] = pu[P0];
-		A.v0[S0] = pv[P0];
-		A.bq[S0] = uniform(pb[P0]);
-		{
-			const ptrdiff_t rb = row_base(jn);
-			pu[P0] = CRD_ROW_LOAD(at_lane_as<V>(a.in_u + rb, xb));
-			pv[P0] = CRD_ROW_LOAD(at_lane_as<V>(a.in_v + rb, xb));
-			pb[P0] = brow[jn];
-			jn = (jn < jlast) ? jn + 1 : jlast;
-		}
+		// row p out of its ring slot (filled kRingRows iterations ago) ...
+		if (m < 4 * kApron + kRingRows) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitFill) : "memory");  // (fewer operations in flight while no rows come out yet)
+		ring_read<kWaitSteady, S0 * SLOT, S0 * SLOT + RB>(ring_trip, A.u0[S0], A.v0[S0]);
+		A.bq[S0] = uniform(pb);
+#ifndef CRD_PROBE_NOLOAD  // (probe builds, tools/build_variant.sh: what a launch costs without its row reads / its second step / its stores)
+		fill(jn, trip_byte + S0 * SLOT);  // ... and row p + kRingRows into it
+#endif
+		jn = (jn < jlast) ? jn + 1 : jlast;
+		pb = brow[(p < jlast) ? p + 1 : jlast];
 		V nu, nv;
+#ifdef CRD_PROBE_NOMATH  // (probe build: the launch as a copy -- its memory traffic alone)
+		nu = A.u0[S0] + (V)b4a;
+		nv = A.v0[S0] + (V)b4b;
+#else
 		stages(A, p, kk, 0, b4a, nu, nv);  // step n: the new row p - 4 ...
+#endif
+#if !defined(CRD_PROBE_HALFMATH) && !defined(CRD_PROBE_NOMATH)
 		B.u0[S0] = nu;                            // ... is the second pipeline's newest row (same slot: rows shifted by 4)
 		B.v0[S0] = nv;
 		B.bq[S0] = b4a;
 		stages(B, p - kApron, kk, 4, b4b, nu, nv);  // step n + 1: the new row p - 8
+#endif
+#ifndef CRD_PROBE_NOSTORE
 		if (m >= 4 * kApron && lane_stores) {  // rows j0 .. j1 - 1 exactly
-			row_store<NT>(at_lane_as<V>(out_row_u, ob), nu);
-			row_store<NT>(at_lane_as<V>(out_row_v, ob), nv);
+			buffer_row_store<NT>(row_resource(out_row_u), xb, nu);
+			buffer_row_store<NT>(row_resource(out_row_v), xb, nv);
 		}
+#else
+		if (m >= 4 * kApron && lane_stores && a.nchunks < 0) {  // (never: keeps the arithmetic alive)
+			buffer_row_store<NT>(row_resource(out_row_u), xb, nu);
+			buffer_row_store<NT>(row_resource(out_row_v), xb, nv);
+		}
+#endif
 		out_row_u += nx;
 		out_row_v += nx;
 	};
+	auto next_trip = [&]() {
+		if constexpr (kRingRows > M) {
+			trip_byte = (trip_byte + M * SLOT) & (kRingRows * SLOT - 1);
+			ring_trip = ring_lane + (unsigned)trip_byte;
+		}
+	};
 	int m = 0;
-	for (; m + M - 1 < niter; m += M)
+	for (; m + M - 1 < niter; m += M) {
 		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k); }, std::make_integer_sequence<int, M>{});
+		next_trip();
+	}
 	for_sequence(
 	    [&](auto k) {
 		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k);
 	    },
 	    std::make_integer_sequence<int, M - 1>{});
+	// the fills still in flight write LDS: they must have landed before the wavefront ends and its LDS goes to the next workgroup
+	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ABSORB = false: no stage of the step has t < tBoundary (every launch after the switch-off time, every launch of a run with
@@ -639,8 +746,11 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 // (src/FHNmodel_torus.cpp:643-653) run the body with the selects, all others the body without (see fused_item).
 // EMBED, COLS, NT: see FusedArgs / fused_item above.
 // STEPS = 2: two steps per launch (fused_item_two_steps).
+// Wavefronts per SIMD the register allocator is held to: the two-step pipelines live at the 168-register line (three wavefronts).
+template <typename Real, int MODEL, int COLS, int STEPS, bool ABSORB>
+constexpr int kMinWaves = (STEPS == 2 && COLS * (int)sizeof(Real) == 8 && MODEL == CRD_MODEL_FHN && !ABSORB) ? 3 : 1;
 template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false, int STEPS = 1>
-__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
+__global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kMinWaves<Real, MODEL, COLS, STEPS, ABSORB>))) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
 	static_assert(STEPS == 1 || (STEPS == 2 && EMBED == 0), "two steps per launch: the plain step only");
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
@@ -671,6 +781,9 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 	const int strip = __builtin_amdgcn_readfirstlane(sblk * a.sw + (int)(threadIdx.x >> 6));
 	const int chunk = __builtin_amdgcn_readfirstlane(cblk);
 	if (strip >= a.nstrips || chunk >= a.nchunks) return;  // (a barrier waits for the surviving wavefronts of the workgroup only)
+	// the row rings of a two-step launch's wavefronts (fused_item_two_steps)
+	__shared__ __attribute__((aligned(16))) char rings[STEPS == 2 ? kRingBytes<Real, COLS> : 16];
+	lds_char *const block_rings = (lds_char *)rings;
 	if constexpr (ABSORB) {
 		// Does any row this chunk's pipeline touches -- [j0 - APRON, j1 + APRON) -- map to global row 0 or ny - 1?  The two are
 		// neighbours on the periodic grid: the rows contain one of them exactly when [lo, hi + 1] contains a multiple of ny.
@@ -681,14 +794,14 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) crd_rk4_fused_step_
 		const int lo = a.js + j0 - APRON, hi1 = a.js + j1 + APRON;  // (lo > -ny and hi1 < 3 ny: a slab is at most the grid, ghost rows at most a slab)
 		const bool touches = (lo <= 0 && 0 <= hi1) || (lo <= a.ny && a.ny <= hi1) || (lo <= 2 * a.ny && 2 * a.ny <= hi1);
 		if constexpr (STEPS == 2) {
-			if (touches) fused_item_two_steps<Real, MODEL, true, COLS, NT>(s, a, strip, chunk);
-			else fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk);
+			if (touches) fused_item_two_steps<Real, MODEL, true, COLS, NT>(s, a, strip, chunk, block_rings);
+			else fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk, block_rings);
 		} else {
 			if (touches) fused_item<Real, MODEL, true, EMBED, COLS, NT>(s, a, strip, chunk);
 			else fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
 		}
 	} else if constexpr (STEPS == 2) {
-		fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk);
+		fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk, block_rings);
 	} else {
 		fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
 	}

@@ -59,6 +59,12 @@ void build_coefficients(const crd_params &p, const crd_grid &g, Coefficients *ou
 		const double cu2 = D / g.dy / g.dy;
 		for (int64_t i = 0; i < g.nx; i++) out->cP[(size_t)i] = cu2;
 	}
+	out->cE.resize((size_t)g.nx);
+	out->cWn.resize((size_t)g.nx);
+	for (int64_t i = 0; i < g.nx; i++) {
+		out->cE[(size_t)i] = out->cX + out->cA[(size_t)i];
+		out->cWn[(size_t)i] = out->cA[(size_t)i] - out->cX;
+	}
 }
 
 void build_beta_rows(const crd_params &p, const crd_grid &g, int64_t j0, int64_t j1, std::vector<double> *out)

@@ -37,10 +37,14 @@ constexpr int kGhost = kStepHalo * kMaxExchangeEvery;
 // Host-side coefficient tables of the diffusion operator written as
 //   du = cA[i] (uE - uW) + cX (uE - 2 uC + uW) + cP[i] (uN - 2 uC + uS)
 // (torus: src/FHNmodel_torus.cpp:535-537; flat: cA = 0, cX = D/dx^2, cP = D/dy^2, src/FHNmodel_flat.cpp:489-491).
+// The kernels take the theta part on first differences, cA (uE - uW) + cX (uE - 2 uC + uW) = cE (uE - uC) + cWn (uC - uW) with
+// cE[i] = cX + cA[i], cWn[i] = cA[i] - cX (crd_device.h: rhs_point).
 struct Coefficients {
-	std::vector<double> cA;  // nx
-	std::vector<double> cP;  // nx
+	std::vector<double> cA;   // nx
+	std::vector<double> cP;   // nx
 	double cX = 0.0;
+	std::vector<double> cE;   // nx
+	std::vector<double> cWn;  // nx
 };
 void build_coefficients(const crd_params &p, const crd_grid &g, Coefficients *out);
 

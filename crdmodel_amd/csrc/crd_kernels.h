@@ -17,10 +17,10 @@ struct Planes {
 
 // Everything a kernel needs to know about the slab; passed by value as a kernel argument.
 struct SlabDesc {
-	const void *cA;    // nx: advection coefficient  D (-sin th / (r rho)) / (2 dx)     (0 for flat)
+	const void *cE;    // nx: cX + cA[i], coefficient of uE - uC   (cA = D (-sin th / (r rho)) / (2 dx), 0 for flat;
+	const void *cWn;   // nx: cA[i] - cX, coefficient of uC - uW    cX = D / r^2 / dx^2, D/dx^2 for flat)
 	const void *cP;    // nx: phi-diffusion coefficient D / rho^2 / dy^2                 (D/dy^2 for flat)
-	const void *brow;  // nyl + 2*kGhost: b(j) per local row, index j + kGhost
-	double cX;         // theta-diffusion coefficient D / r^2 / dx^2                     (D/dx^2 for flat)
+	const void *brow;  // nyl + 2*kGhost: the kinetics' row parameter (FHN: EPSILON b(j); Goldbeter: v0 + v1 b(j)), index j + kGhost
 	double ka4;        // Goldbeter pow(KA, p)
 	int nx;
 	int nyl;

@@ -110,7 +110,8 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, S
 		const Real *row = a.in_u + (ptrdiff_t)wrap_row(s, jt) * nx;
 		tile[tr][tx + 1] = row[i];
 	}
-	const Real cA = col_ok ? s.cA[i] : (Real)0;
+	const Real cE = col_ok ? s.cE[i] : (Real)0;
+	const Real cWn = col_ok ? s.cWn[i] : (Real)0;
 	const Real cP = col_ok ? s.cP[i] : (Real)0;
 	__syncthreads();
 
@@ -121,7 +122,7 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rk4_stage_kernel(Slab<Real> s, S
 		const int tr = ty + kBY * r + 1;
 		const bool zero = a.absorb && ((s.has_row0 && j == 0) || (s.has_rowN && j == s.nyl - 1));
 		Real du, dv;
-		rhs_point<Real, MODEL>(uC[r], tile[tr][tx], tile[tr][tx + 2], tile[tr - 1][tx + 1], tile[tr + 1][tx + 1], vC[r], cA, s.cX, cP,
+		rhs_point_values<Real, MODEL>(uC[r], tile[tr][tx], tile[tr][tx + 2], tile[tr - 1][tx + 1], tile[tr + 1][tx + 1], vC[r], cE, cWn, cP,
 		                       s.brow[j], s.ka4, zero, du, dv);
 		const size_t o = (size_t)j * nx + i;
 		if (STAGE == 0) {
@@ -187,7 +188,8 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, con
 		else val = (jt < 0) ? ghost_lo[i] : ghost_hi[i];
 		tile[tr][tx + 1] = val;
 	}
-	const Real cA = col_ok ? s.cA[i] : (Real)0;
+	const Real cE = col_ok ? s.cE[i] : (Real)0;
+	const Real cWn = col_ok ? s.cWn[i] : (Real)0;
 	const Real cP = col_ok ? s.cP[i] : (Real)0;
 	__syncthreads();
 
@@ -198,7 +200,7 @@ __global__ void __launch_bounds__(kTX *kBY) crd_rhs_aos_kernel(Slab<Real> s, con
 		const int tr = ty + kBY * r + 1;
 		const bool zero = absorb && ((s.has_row0 && j == 0) || (s.has_rowN && j == nyl - 1));
 		P k;
-		rhs_point<Real, MODEL>(own[r].x, tile[tr][tx], tile[tr][tx + 2], tile[tr - 1][tx + 1], tile[tr + 1][tx + 1], own[r].y, cA, s.cX, cP,
+		rhs_point_values<Real, MODEL>(own[r].x, tile[tr][tx], tile[tr][tx + 2], tile[tr - 1][tx + 1], tile[tr + 1][tx + 1], own[r].y, cE, cWn, cP,
 		                       s.brow[j], s.ka4, zero, k.x, k.y);
 		pair_store<NT, Real>(&ydot[(size_t)j * nx + i], k);
 	}

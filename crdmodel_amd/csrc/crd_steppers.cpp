@@ -2,6 +2,7 @@
 // slab or on the slabs of a run (deep-halo exchange cycles), and the error-controlled RK4(3) integrator.  Host code only.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <thread>
 
@@ -939,6 +940,9 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			if ((rc = finish_attempt(my_slot, &sum))) break;
 			dsm = std::sqrt(sum / n_components);
 			st.err_last = dsm;
+#ifdef CRD_TUNING_BUILD
+			if (std::getenv("CRD_ADAPT_TRACE")) std::fprintf(stderr, "libcrd attempt: t %.17g h %.17g sum %.17g\n", t, A.h, sum);
+#endif
 			if (dsm <= 1.0) break;  // (a NaN fails the test)
 			ahead.live = false;     // a failed step: what was launched ahead of it is void
 			nef++;

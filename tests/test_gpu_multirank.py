@@ -140,9 +140,13 @@ def test_error_controlled_integration_on_a_ring_of_processes(gpu_device, standin
     assert single_stats[:, 0].min() >= 2
     # Against the single slab the norm is summed in another order: where the controller sits at a limit, a last-bit difference can
     # change a later step size, and the step sequences part (then the states agree to the integrator's tolerance, not to round-off).
-    same = np.array_equal(ring_stats[0][:, :2], single_stats[:, :2]) and np.allclose(ring_stats[0][:, 2], single_stats[:, 2], rtol=1e-9, atol=0.0)
+    # (How far a last-bit difference goes: measured on the 3-rank case, round 5 -- one ulp in an attempt's step size moves that attempt's
+    # error sum by 4e-10 relative, the estimate being a difference of O(h f) terms that cancel to O(h^5), and the step sizes of the
+    # following attempts by 1e-11 ... 1e-8.  Same decisions and step sizes to 1e-6 is what "the same sequence" means here; the STATES
+    # below are held to round-off.)
+    same = np.array_equal(ring_stats[0][:, :2], single_stats[:, :2]) and np.allclose(ring_stats[0][:, 2], single_stats[:, 2], rtol=1e-6, atol=0.0)
     first_calls = ring_stats[0][:2], single_stats[:2]
-    assert np.array_equal(first_calls[0][:, :2], first_calls[1][:, :2]) and np.allclose(first_calls[0][:, 2], first_calls[1][:, 2], rtol=1e-9, atol=0.0), first_calls
+    assert np.array_equal(first_calls[0][:, :2], first_calls[1][:, :2]) and np.allclose(first_calls[0][:, 2], first_calls[1][:, 2], rtol=1e-6, atol=0.0), first_calls
     for k, (a, b) in enumerate(zip(ring, single)):
         assert rel(a, b) <= (1e-9 if same or k < 2 else 1e-5), "snapshot %d: %.3e" % (k, rel(a, b))
 
