@@ -681,7 +681,10 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		constexpr int K = decltype(kk)::value;
 		constexpr int S0 = K % M, S4 = (K + 2 * M - 4) % M;
 #if !defined(CRD_NO_LOCKSTEP) && !defined(CRD_NO_LOCKSTEP_TWO)
-		__builtin_amdgcn_s_barrier();
+		// Lockstep of the block's wavefronts: fp32 only.  With the rows coming through the rings, the fp64 pipelines run 1 - 5 % faster
+		// when their wavefronts drift (8192^2 FHN 0.2292 -> 0.2251 ms per step, 4096^2 0.0683 -> 0.0663, Goldbeter 4096^2 0.1212 -> 0.1148),
+		// the packed fp32 one 2 % slower (16384^2 0.4230 -> 0.4308; profiles/r05/two_step_memory_path_ab.txt).
+		if constexpr (sizeof(Real) == 4) __builtin_amdgcn_s_barrier();
 #endif
 		const int p = jbase + m;
 		const Real b4a = A.bq[S4], b4b = B.bq[S4];
