@@ -1,52 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- grid-point-steps/s of the HIP RK4 path on the BASELINE.json workload (FHN torus 8192^2, fp64).
 
-    python bench.py [--gpus N --steps K --warmup W]           # N = 1; N > 1: bench.py starts its own N rank processes (below)
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-           bench.py --gpus N --steps K --warmup W              # one rank per GPU, phi-slabs, RCCL halos
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
-Started as plain `python bench.py --gpus N` with N > 1 (no WORLD_SIZE in the environment) the script is its own launcher, the way
-the reference's scripts say `mpirun -np 4` (util/ShellScripts/runFHNmodelTorus.sh:6): before it imports torch or touches HIP it
-starts N fresh rank processes of itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1, a free port), passes rank 0's
-line through and exits with the worst child status.  `--transport rccl` (one process per GPU, the ring of ncclSend / ncclRecv) is
-what that does; `--transport local` steps the same slabs as a LOCAL group inside ONE process (device-to-device peer copies, one
-issuing host thread per GPU, crd_group_step_rk4); `--transport auto` (default) tries rccl first and, should the ring fail to come
-up or to finish, runs the local leg so that a first contact with an 8-GPU node still yields a scaling number -- the line says which
-transport it measured and why (`config.launcher`).  Ranks started by SOMEBODY ELSE'S launcher (the second form above: no launcher
-of ours to run that leg) fall back too: each rank brings the ring up in a helper thread it stops waiting for after
---ring-timeout-s, the ranks tell each other over the control plane how that went, and if it failed anywhere ranks 1.. leave with
-status 0 while rank 0 runs the local leg in a child process and passes its line on (`ring_failed`).
+A "step" is one classical RK4 step of the whole grid on synthetic initial conditions made by the reference's own rule; the state
+is resident in HBM before the timed region; the grid is fixed as N grows (strong scaling); rank r owns phi-slab r of N; rank 0
+prints ONE JSON line.  Order of a run: set-up and halo self-check, launch-plan measurement (crd_plan_launches, or --launch-plan),
+rehearsals (N > 1), --preheat-ms of untimed stepping, W warm-up steps, K timed steps between two fences (MAX over ranks).
 
-A "step" is one classical RK4 step of the whole grid (4 RHS evaluations with fused stage updates) on synthetic
-initial conditions generated by the reference's own rule; the state is resident in HBM before the timed region.
-The grid is fixed as N grows (strong scaling); rank r owns phi-slab r of N.  Rank 0 prints ONE JSON line.
+How N > 1 runs -- one state machine, whoever starts it:
 
-The line's `roofline` prices the dominant kernel by ITS OWN algorithmic bytes (the one-launch step: read + write of the
-state once, 4 reals per point; `frac` <= 1), keeps SURVEY 8(d)'s 32-reals-per-step figure under `survey_8d_equivalent`, and
-measures that scheme for real in the `staged` sub-record (four stage kernels per step, timed in this same process before the
-main run, N = 1).  `config.launch_plan` is the work-item plan the library measured for this grid on this device;
-`config.halo` says which transport moved the halos and, under RCCL, what the communicator reports about itself and the
-result of a one-exchange self-check (ghost rows == the neighbours' owned rows) made on every rank before anything is timed.
+    START --(WORLD_SIZE unset, N > 1, transport != local)--> SELF-LAUNCH: this process touches no GPU, starts N rank processes of
+          itself (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, 127.0.0.1, a free port) and watches ALL of them
+    RANK  (started by us or by torch.distributed.run): roll call over gloo -> RING BRING-UP in a helper thread the rank stops
+          waiting for after --ring-timeout-s (ncclCommInitRank, communicator self-report, 32-row halo self-check) -> the ranks
+          tell each other how it went (AGREED OUTCOME) -> ok: rehearsals, timed region, rank 0 prints the line
+    ring failed anywhere, --transport auto -> LOCAL LEG: ONE fresh child process steps all N slabs as a LOCAL group (peer copies,
+          one issuing host thread per GPU).  Under our launcher the ranks leave with status 4 and the launcher starts that child;
+          under an external launcher ranks 1.. leave with status 0 and rank 0 starts it and passes its line on.  A process that has
+          touched the GPU is never replaced.  config.launcher says which way the line came; --transport rccl / local pin a leg.
+    The legs share one time budget (--launch-timeout-s in all): the LOCAL leg gets what the ring's leg left.
 
-Order of a run: set-up and self-check, launch-plan measurement (`crd_plan_launches`; or a plan pinned with --launch-plan), `--preheat-ms`
-of untimed stepping (default 300 ms: the timed region may be 20 steps = 8 ms, and behind the upload the device has idled -- the
-clocks of a long run are the ones worth reporting; `config.preheat` says how many steps that was), the W warm-up steps, then the K
-timed steps between two fences.
-
-PyTorch is used only for process-group plumbing, and that plumbing is a GLOO group on CPU tensors (barrier, max / sum
-reductions, broadcast of the 128-byte RCCL id, gather of the per-rank diagnostics): each process owns exactly ONE RCCL
-communicator -- libcrd's, the one that moves the halos.  All arithmetic is in libcrd's HIP kernels.  The oracle is used only
-for the `cpu_baseline` leg.
-
-N > 1 lines carry `per_rank`: every rank's own kernel time, step time and launch plan from the timed region, and -- from a
-short diagnostic pass AFTER the timed region (crd_set_diagnostics puts event records between sweeps, so it is kept out of the
-rate) -- how long the rank's compute stream stood waiting for a halo per exchange (`exposed_halo_ms`) and how long an exchange
-took on the second stream (`exchange_ms`).
-"""
+`roofline` prices the dominant kernel by ITS OWN compulsory bytes (the one-launch step: read + write of the state once per
+launch, 4 reals per point), measured live with HIP events on the library's stream; `issue_frac` is the same launch on the
+vector-issue roof, from the instruction count of the kernel's loop in the build's own assembly (crd_get_launch_geometry);
+`bound` names the roof the launch sits closer to.  SURVEY 8(d)'s 32-reals-per-step scheme is measured in `staged`.
+PyTorch is plumbing only: a GLOO group on CPU tensors; each rank owns ONE RCCL communicator, libcrd's.  The oracle is used only
+by the `cpu_baseline` leg."""
 import argparse
-import datetime
 import json
 import os
+import subprocess
 import sys
 import time
 import traceback
@@ -55,11 +40,13 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+from crdmodel_amd.benchkit import ControlPlane, committed_json, halo_selfcheck, measured_traffic, selfcheck_ghost_rows, selfcheck_pattern, usable_cores  # noqa: E402,F401 (no GPU, no libcrd yet)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-# Algorithmic HBM bytes: 32 reals per grid-point-step = 6 (stage 1) + 10 + 10 (stages 2, 3) + 6 (stage 4).
-REALS_PER_POINT_STEP = 32
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+REALS_PER_POINT_STEP = 32  # 6 (stage 1) + 10 + 10 (stages 2, 3) + 6 (stage 4) reals per grid-point-step, staged scheme
 REALS_PER_POINT_STAGE23 = 10
+LAUNCHER_VARS = ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "GLOO_SOCKET_IFNAME",
+                 "CRD_BENCH_SELF_LAUNCHED")
 
 
 def parse(argv=None):
@@ -77,199 +64,49 @@ def parse(argv=None):
     ap.add_argument("--cpu-rows", type=int, default=4096, help="phi rows of the grid the CPU baseline integrates")
     ap.add_argument("--cpu-steps", type=int, default=72, help="RK4 steps of the CPU baseline (about 12 s on 16 cores)")
     ap.add_argument("--force-rccl", action="store_true", help="world size 1 only: route the halos through an RCCL ring to self (rehearses the N>1 code path)")
-    ap.add_argument("--halo-slack-threshold-ms", type=float, default=0.03,
-                    help="ring runs: exposed wait per exchange (max over ranks, rehearsal) above which the halo gets a third sweep of cover")
-    ap.add_argument("--preheat-ms", type=float, default=300.0,
-                    help="untimed stepping in front of the W warm-up steps, so that a short timed region runs at the clocks a long run settles at "
-                         "(0 = none); the step count is agreed between the ranks and reported in config.preheat")
-    ap.add_argument("--launch-plan", default="", metavar="MODE,MAPPING,COLUMNS[,NT[,STEPS]]",
-                    help="pin the step kernel's launch plan (crd_set_launch_plan) instead of measuring it, e.g. the config.launch_plan of an earlier run: "
-                         "under rocprofv3 every launch of the kernel is then the plan that is timed")
-    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "local"],
-                    help="N > 1: rccl = one rank process per GPU (self-launched unless a launcher set WORLD_SIZE); local = one process, LOCAL group; "
-                         "auto = rccl, and local if that fails")
-    ap.add_argument("--ring-timeout-s", type=float, default=150.0, help="give up (exit status 4) if the RCCL ring is not up and self-checked within this long (0 = wait for ever)")
-    ap.add_argument("--launch-timeout-s", type=float, default=240.0,
-                    help="self-launched legs: give up on a leg (and end its processes) after this long -- a healthy 8-rank run takes about a minute, and a ring "
-                         "that hangs at first contact must leave the LOCAL leg time to run inside the caller's own limit")
+    ap.add_argument("--halo-slack-threshold-ms", type=float, default=0.03, help="ring runs: exposed wait per exchange (max over ranks) above which the halo gets a third sweep of cover")
+    ap.add_argument("--preheat-ms", type=float, default=300.0, help="untimed stepping in front of the warm-up, so that a short timed region runs at the clocks a long run settles at")
+    ap.add_argument("--launch-plan", default="", metavar="MODE,MAPPING,COLUMNS[,NT[,STEPS]]", help="pin the step kernel's launch plan (crd_set_launch_plan) instead of measuring it")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "local"], help="N > 1: rccl = one rank process per GPU; local = one process, LOCAL group; auto = rccl, then local")
+    ap.add_argument("--ring-timeout-s", type=float, default=150.0, help="a rank stops waiting for the RCCL ring's bring-up after this long (0 = wait for ever)")
+    ap.add_argument("--launch-timeout-s", type=float, default=420.0, help="time budget of ALL legs of an N > 1 run together (a healthy 8-rank run takes about a minute)")
     ap.add_argument("--exchange-period", type=int, default=0, help="ring runs: fused steps per deep-halo exchange; 0 = rehearse 8 and 16, keep the faster")
     ap.add_argument("--devices", default="", help="--transport local: device ordinal of each slab, e.g. 0,0 to rehearse two slabs on one GPU (default 0..N-1)")
     ap.add_argument("--issuing-threads", type=int, default=0, help="--transport local: host threads issuing the group's work (0 = one per device)")
     ap.add_argument("--crd-module", default="crdmodel_amd", help=argparse.SUPPRESS)  # tests: a stand-in for the device API (tests/standin_crd.py)
-    ap.add_argument("--repeats", type=int, default=4, help="the K timed steps again, this many times, AFTER the timed region: how much the figure varies (not part of `value`)")
-    ap.add_argument("--one-step-steps", type=int, default=40, help="steps of the one-step-per-launch kernel timed beside a two-step run for roofline.one_step_per_launch (0 = skip)")
+    ap.add_argument("--repeats", type=int, default=4, help="the K timed steps again, this many times, AFTER the timed region (spread of the figure; not part of `value`)")
+    ap.add_argument("--one-step-steps", type=int, default=40, help="steps of the one-step-per-launch kernel timed beside a two-step run (0 = skip)")
     ap.add_argument("--staged-steps", type=int, default=40, help="steps of the staged stepper timed beside a fused run for the `staged` sub-record (0 = skip)")
     return ap.parse_args(argv)
 
 
-def usable_cores():
-    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota (16 on a 1-GPU box)."""
-    n = len(os.sched_getaffinity(0))
-    try:
-        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
-        if quota != "max":
-            n = min(n, max(1, int(int(quota) // int(period))))
-    except (OSError, ValueError):
-        pass
-    return max(1, n)
-
-
-def measured_traffic(kernel_key, points):
-    """(HBM bytes per launch, where the figure comes from).  PMC counters cannot be collected by the benchmark itself (they
-    need rocprofv3 around the process), so this is the committed result of separate `rocprofv3 --pmc FETCH_SIZE` /
-    `--pmc WRITE_SIZE` passes of this same command (profiles/pmc_traffic.json: bytes per grid point, FETCH doubled as the
-    gfx950 guide prescribes), scaled by the points one launch of this run covers.  (None, reason) when there is no such record."""
-    try:
-        table = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-    except (OSError, ValueError):
-        return None, "no profiles/pmc_traffic.json"
-    rec = table.get(kernel_key)
-    if not rec:
-        return None, "no rocprofv3 --pmc passes recorded for %s" % kernel_key
-    return rec["bytes_per_point"] * points, "%s: %.2f B/point on %s, rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE in separate passes; not re-measured by this run" % (
-        rec.get("source", "profiles/pmc_traffic.json"), rec["bytes_per_point"], rec.get("grid", "?"))
-
-
-def committed_json(name):
-    """profiles/<name> as a dict ({} when absent): measurements this run does not repeat but quotes, with their provenance."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", name)))
-    except (OSError, ValueError):
-        return {}
-
-
-def selfcheck_pattern(rows, nx, var, dtype):
-    """The self-check field on global rows `rows`: value = f(global row, column, variable), exactly representable in fp32 too
-    (integers below 2^24)."""
-    rows = np.asarray(rows, dtype=np.int64)
-    return (((rows[:, None] * 7919 + np.arange(nx, dtype=np.int64)[None, :] * 31 + var * 5) % 16777213).astype(np.float64)).astype(dtype)
-
-
-def selfcheck_ghost_rows(js, je, ny, depth):
-    """Global rows a slab [js, je] of a periodic ny-row grid must find in its low / high ghost rows after an exchange of `depth`."""
-    return np.arange(js - depth, js) % ny, np.arange(je + 1, je + 1 + depth) % ny
-
-
-def halo_selfcheck(crd, slab, rank, world, depth=32):
-    """Did the transport move the right rows?  Every rank uploads the self-check field, runs ONE exchange of `depth` ghost rows
-    through the library's own transport and compares its ghost rows with the rows its ring neighbours own.  Returns the number
-    of mismatching values on this rank (0 = ok).  (The expectation side of this check runs over gloo with 2 and 3 ranks in
-    tests/test_distributed_cpu.py.)"""
-    nx, nyl, ny = slab.nx, slab.nyl, slab.grid.ny
-    own = np.arange(slab.js, slab.je + 1)
-    y = np.empty((nyl, nx, 2), dtype=np.float64)
-    y[..., 0], y[..., 1] = selfcheck_pattern(own, nx, 0, slab.dtype), selfcheck_pattern(own, nx, 1, slab.dtype)
-    slab.upload(y)
-    slab.halo_exchange(depth)
-    lo_rows, hi_rows = selfcheck_ghost_rows(slab.js, slab.je, ny, depth)
-    bad = 0
-    for var in (0, 1):
-        bad += int(np.count_nonzero(slab.download_rows(var, -depth, depth) != selfcheck_pattern(lo_rows, nx, var, slab.dtype)))
-        bad += int(np.count_nonzero(slab.download_rows(var, nyl, depth) != selfcheck_pattern(hi_rows, nx, var, slab.dtype)))
-    return bad
-
-
-class ControlPlane:
-    """Everything the ranks of a run tell each other outside the halo exchange, over a gloo group on CPU tensors.  (The halos
-    travel through libcrd's own RCCL communicator; a second, torch-owned RCCL communicator beside it would be one more thing
-    to go wrong on first contact with an 8-GPU node, and nothing here needs the GPU.)  world == 1: no group at all."""
-
-    def __init__(self, world, rank, timeout_s=300):
-        self.world, self.rank, self.dist = world, rank, None
-        if world > 1:
-            import torch.distributed as dist
-
-            # one node: loopback is always there, the hostname may not resolve.  Ranks on several nodes: leave the interface to gloo.
-            if int(os.environ.get("LOCAL_WORLD_SIZE", str(world))) == world:
-                os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            if not dist.is_initialized():
-                dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=timeout_s))
-            self.dist = dist
-
-    def barrier(self):
-        if self.dist:
-            self.dist.barrier()
-
-    def _reduce(self, values, dtype, op):
-        import torch
-
-        t = torch.tensor(list(values), dtype=dtype)
-        if self.dist:
-            self.dist.all_reduce(t, op=op)
-        return t.tolist()
-
-    def sum_ints(self, values):
-        import torch
-        import torch.distributed as dist
-
-        return [int(v) for v in self._reduce(values, torch.int64, dist.ReduceOp.SUM)]
-
-    def max_float(self, value):
-        import torch
-        import torch.distributed as dist
-
-        return float(self._reduce([value], torch.float64, dist.ReduceOp.MAX)[0])
-
-    def broadcast_bytes(self, payload, nbytes, src=0):
-        """`payload` (bytes, on rank `src`; ignored elsewhere) to every rank."""
-        if not self.dist:
-            return payload
-        import torch
-
-        t = torch.zeros(nbytes, dtype=torch.uint8)
-        if self.rank == src:
-            t.copy_(torch.frombuffer(bytearray(payload), dtype=torch.uint8))
-        self.dist.broadcast(t, src=src)
-        return bytes(t.numpy().tobytes())
-
-    def gather(self, obj):
-        """[rank 0's obj, rank 1's obj, ...] on every rank."""
-        if not self.dist:
-            return [obj]
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
-        return out
-
-    def close(self):
-        if self.dist and self.dist.is_initialized():
-            self.dist.destroy_process_group()
-        self.dist = None
-
-
-def cpu_baseline(args, params_kw, dt):
+def cpu_baseline(args, beta, dt):
     """The oracle (a port of the reference's f() + classical RK4) timed on this box's host cores, on a bounded band."""
     from oracle import crd_oracle as co
 
-    threads = usable_cores()
-    rows = min(args.cpu_rows, args.size)
+    threads, rows = usable_cores(), min(args.cpu_rows, args.size)
     model = co.FHN if args.model == "fhn" else co.GOLDBETER
-    op = co.make_problem(model, co.TORUS, args.size, 80.0, 20.0, 0.12, params_kw["beta"], ny=rows)
-    op.dy = (2.0 * 3.1415926535897932) / (1.0 * args.size - 1.0)  # the band keeps the full grid's phi spacing
-    y0 = co.initial_conditions(op, 0.1, 0.5, 0, 0)
-    co.rk4(op, y0, 0.0, dt, 1, nthreads=threads)  # warm-up (page faults, OpenMP pool)
-    t0 = time.perf_counter()
-    co.rk4(op, y0, 0.0, dt, args.cpu_steps, nthreads=threads)
-    el = time.perf_counter() - t0
-    # the same code on ONE core, on a band an eighth as tall and a few steps (SURVEY 8d asks for both figures)
-    rows1, steps1 = max(16, rows // 8), max(1, args.cpu_steps // 18)
-    op1 = co.make_problem(model, co.TORUS, args.size, 80.0, 20.0, 0.12, params_kw["beta"], ny=rows1)
-    op1.dy = op.dy
-    y1 = co.initial_conditions(op1, 0.1, 0.5, 0, 0)
-    t0 = time.perf_counter()
-    co.rk4(op1, y1, 0.0, dt, steps1, nthreads=1)
-    el1 = time.perf_counter() - t0
-    return {
-        "value": args.size * rows * args.cpu_steps / el,
-        "unit": "grid-point-steps/s",
-        "cores": threads,
-        "kind": "port",
-        "sample": "%dx%d band of the %dx%d grid, %d RK4 steps, faithful per-point sin/cos RHS (oracle/crd_oracle.c), OpenMP over rows, %.1f s"
-                  % (args.size, rows, args.size, args.size, args.cpu_steps, el),
-        "value_1core": args.size * rows1 * steps1 / el1,
-        "sample_1core": "%dx%d band, %d RK4 steps, one thread, %.1f s" % (args.size, rows1, steps1, el1),
-    }
+
+    def band(ny, steps, nthreads):
+        op = co.make_problem(model, co.TORUS, args.size, 80.0, 20.0, 0.12, beta, ny=ny)
+        op.dy = (2.0 * 3.1415926535897932) / (1.0 * args.size - 1.0)  # the band keeps the full grid's phi spacing
+        y0 = co.initial_conditions(op, 0.1, 0.5, 0, 0)
+        if nthreads > 1:
+            co.rk4(op, y0, 0.0, dt, 1, nthreads=nthreads)  # warm-up (page faults, OpenMP pool)
+        t0 = time.perf_counter()
+        co.rk4(op, y0, 0.0, dt, steps, nthreads=nthreads)
+        return time.perf_counter() - t0
+
+    el = band(rows, args.cpu_steps, threads)
+    rows1, steps1 = max(16, rows // 8), max(1, args.cpu_steps // 18)  # the same code on ONE core (SURVEY 8d asks for both figures)
+    el1 = band(rows1, steps1, 1)
+    return {"value": args.size * rows * args.cpu_steps / el, "unit": "grid-point-steps/s", "cores": threads, "kind": "port",
+            "sample": "%dx%d band of the %dx%d grid, %d RK4 steps, faithful per-point sin/cos RHS (oracle/crd_oracle.c), OpenMP over rows, %.1f s"
+                      % (args.size, rows, args.size, args.size, args.cpu_steps, el),
+            "value_1core": args.size * rows1 * steps1 / el1, "sample_1core": "%dx%d band, %d RK4 steps, one thread, %.1f s" % (args.size, rows1, steps1, el1)}
 
 
+# ---- the launcher side of the state machine (module docstring) ---------------------------------------------------------------------
 def free_port():
     import socket
 
@@ -289,102 +126,128 @@ def last_json_line(text):
     return None
 
 
-def spawn_ranks(args, argv):
-    """N rank processes of this script, one per GPU (what `torch.distributed.run --nproc-per-node N` would start): RANK, LOCAL_RANK,
-    WORLD_SIZE, LOCAL_WORLD_SIZE, MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT in each child's environment.  Returns (rank 0's JSON
-    line as a dict or None, reason).  The children are fresh processes started by a parent that has not touched the GPU; a rank that
-    outlives the limit, or the others' failure, is ended by its exact PID."""
-    import subprocess
+def without_transport(argv):
+    out, skip = [], False
+    for a in argv:
+        if skip or a == "--transport" or a.startswith("--transport="):
+            skip = (a == "--transport")
+            continue
+        out.append(a)
+    return out
 
-    n = args.gpus
-    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0",
-                CRD_BENCH_SELF_LAUNCHED="1")  # (a rank of ours whose ring fails just leaves: the LOCAL leg is this launcher's to run)
-    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv) + ["--transport", "rccl"]
-    procs = []
-    for r in range(n):
-        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=(r == 0)))
-    deadline = time.monotonic() + args.launch_timeout_s
-    out0, why = "", ""
-    try:
-        out0, _ = procs[0].communicate(timeout=max(1.0, deadline - time.monotonic()))
-        for pr in procs[1:]:
-            pr.wait(timeout=max(1.0, min(60.0, deadline - time.monotonic())))
-    except subprocess.TimeoutExpired:
-        why = "rank processes did not finish within %.0f s" % args.launch_timeout_s
-    for pr in procs:  # whoever is still there: end exactly those processes
+
+def end_processes(procs):
+    """End exactly the processes we started that are still there (by PID, never by pattern)."""
+    for pr in procs:
         if pr.poll() is None:
             pr.terminate()
-            try:
-                pr.wait(timeout=10)
-            except subprocess.TimeoutExpired:
-                pr.kill()
-                pr.wait()
+    for pr in procs:
+        try:
+            pr.wait(timeout=10)
+        except subprocess.TimeoutExpired:
+            pr.kill()
+            pr.wait()
+
+
+def ring_leg(args, argv, deadline):
+    """SELF-LAUNCH: N rank processes of this script, one per GPU, watched together: the first rank that exits non-zero ends the leg at
+    once (its siblings would sit in a gloo collective until their time-outs).  Returns (rank 0's line or None, reason)."""
+    n = args.gpus
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0", CRD_BENCH_SELF_LAUNCHED="1")
+    cmd = [sys.executable, os.path.abspath(__file__)] + argv + ["--transport", "rccl"]
+    out0 = open(os.path.join("/tmp", "crd_bench_rank0_%d.out" % os.getpid()), "w+")
+    procs = [subprocess.Popen(cmd, env=dict(base, RANK=str(r), LOCAL_RANK=str(r)), stdout=out0 if r == 0 else subprocess.DEVNULL) for r in range(n)]
+    why = ""
+    while any(pr.poll() is None for pr in procs):
+        if any(pr.returncode not in (None, 0) for pr in procs):
+            break  # somebody failed: no point in waiting for the others' time-outs
+        if time.monotonic() > deadline:
+            why = "rank processes did not finish within the time budget"
+            break
+        time.sleep(0.25)
+    end_processes(procs)
     codes = [pr.returncode for pr in procs]
-    line = last_json_line(out0)
-    if not why and any(codes):
-        why = "rank exit codes %s" % codes
-    if not why and line is None:
-        why = "rank 0 printed no JSON line"
-    return (line if not why else None), why, codes
+    out0.seek(0)
+    line = last_json_line(out0.read())
+    out0.close()
+    os.unlink(out0.name)
+    why = why or ("rank exit codes %s" % codes if any(codes) else ("rank 0 printed no JSON line" if line is None else ""))
+    return (None if why else line), why
+
+
+def local_leg(argv, deadline):
+    """LOCAL LEG: one fresh child process for all GPUs (no launcher variables in its environment).  Returns (line or None, status, reason)."""
+    env = {k: v for k, v in os.environ.items() if k not in LAUNCHER_VARS}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    try:
+        r = subprocess.run([sys.executable, os.path.abspath(__file__)] + without_transport(argv) + ["--transport", "local"], env=env, stdout=subprocess.PIPE, text=True,
+                           timeout=max(20.0, deadline - time.monotonic()))
+    except subprocess.TimeoutExpired:
+        return None, 1, "local: did not finish within the time budget"
+    line = last_json_line(r.stdout)
+    return line, (r.returncode if line is not None else (r.returncode or 1)), ("" if line is not None else "local: exit code %d, no JSON line" % r.returncode)
 
 
 def launch(args, argv):
-    """`python bench.py --gpus N`, N > 1, started without a launcher: be the launcher (module docstring)."""
-    import subprocess
-
-    argv = [a for a in (sys.argv[1:] if argv is None else argv)]
-    # (the transport of each leg is appended by this function)
-    cleaned, skip = [], False
-    for a in argv:
-        if skip:
-            skip = False
-            continue
-        if a == "--transport":
-            skip = True
-            continue
-        if a.startswith("--transport="):
-            continue
-        cleaned.append(a)
-    tried, line, reasons, rc = [], None, [], 1
+    """START without a launcher, N > 1: be the launcher.  Returns the exit status."""
+    argv = without_transport(sys.argv[1:] if argv is None else list(argv))
+    deadline = time.monotonic() + args.launch_timeout_s
+    tried, reasons, line, rc = [], [], None, 1
     if args.transport in ("auto", "rccl"):
         tried.append("rccl")
-        line, why, codes = spawn_ranks(args, cleaned)
+        line, why = ring_leg(args, argv, deadline - (60.0 if args.transport == "auto" else 0.0))  # (auto: the LOCAL leg keeps a minute of the budget at least)
+        rc = 0 if line is not None else 1
         if line is None:
             reasons.append("rccl: " + why)
             sys.stderr.write("bench.py: the rccl leg failed (%s)%s\n" % (why, "; trying --transport local" if args.transport == "auto" else ""))
-        else:
-            rc = 0
     if line is None and args.transport in ("auto", "local"):
         tried.append("local")
-        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-        env.pop("WORLD_SIZE", None)
-        try:
-            r = subprocess.run([sys.executable, os.path.abspath(__file__)] + cleaned + ["--transport", "local"], env=env, stdout=subprocess.PIPE, text=True,
-                               timeout=args.launch_timeout_s)
-            line = last_json_line(r.stdout)
-            rc = r.returncode if line is not None else (r.returncode or 1)
-            if line is None:
-                reasons.append("local: exit code %d, no JSON line" % r.returncode)
-        except subprocess.TimeoutExpired:
-            reasons.append("local: did not finish within %.0f s" % args.launch_timeout_s)
+        line, rc, why = local_leg(argv, deadline)
+        if why:
+            reasons.append(why)
     if line is None:
         raise SystemExit("bench.py --gpus %d: no leg produced a result (%s)" % (args.gpus, "; ".join(reasons)))
-    line.setdefault("config", {})["launcher"] = {"mode": "self-launched: %d rank process(es) started by bench.py itself" % (args.gpus if line["config"].get("halo", {}).get("transport") == "rccl" else 1),
-                                                  "transports_tried": tried, "fallback_reasons": reasons}
+    ranks = args.gpus if line["config"].get("halo", {}).get("transport") == "rccl" else 1
+    line.setdefault("config", {})["launcher"] = {"mode": "self-launched: %d rank process(es) started by bench.py itself" % ranks, "transports_tried": tried, "fallback_reasons": reasons}
     sys.stdout.write(json.dumps(line) + "\n")
     sys.stdout.flush()
     return rc
 
 
+def ring_failed(args, ctl, slab, rank, world, failures, stuck, emit, t_start):
+    """AGREED OUTCOME = failed (every rank knows: the statuses went over the control plane).  Our own launcher, or --transport rccl: every
+    rank leaves with status 4.  An external launcher with --transport auto: ranks 1.. leave with status 0, rank 0 runs the LOCAL LEG in a
+    child and passes its line on.  A rank whose bring-up thread is stuck inside RCCL cannot tear anything down: it leaves through os._exit."""
+    why = "; ".join(failures)
+    relay = args.transport == "auto" and not os.environ.get("CRD_BENCH_SELF_LAUNCHED")
+    if not stuck:
+        slab.close()
+    ctl.close()
+    code = 0 if relay else 4
+    if relay and rank == 0:
+        sys.stderr.write("bench.py: the rccl leg failed (%s); rank 0 runs the LOCAL leg in a child process\n" % why)
+        line, code, lwhy = local_leg(sys.argv[1:], t_start + args.launch_timeout_s)
+        if line is not None:
+            line.setdefault("config", {})["launcher"] = {"mode": "%d rank processes started by an external launcher; the ring failed, rank 0 ran the LOCAL leg in a child process" % world,
+                                                          "transports_tried": ["rccl", "local"], "fallback_reasons": ["rccl: " + why]}
+            emit(json.dumps(line))
+        else:
+            sys.stderr.write("bench.py: no leg produced a result (rccl: %s; %s)\n" % (why, lwhy))
+    elif rank == 0:
+        sys.stderr.write("bench.py: set-up of the ring failed: %s\n" % why)
+    sys.stdout.flush()
+    sys.stderr.flush()
+    os._exit(code) if stuck else sys.exit(code)
+
+
 def main(argv=None):
     args = parse(argv)
+    t_start = time.monotonic()
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's driver only supports dmabuf IPC (RCCL peer buffers)
-    os.environ.setdefault("NCCL_DEBUG", "WARN")  # should the ring fail at first contact, RCCL says why on stderr (silent otherwise)
+    os.environ.setdefault("NCCL_DEBUG", "WARN")  # should the ring fail at first contact, RCCL says why on stderr
     if "WORLD_SIZE" not in os.environ and args.gpus > 1 and args.transport != "local":
         sys.exit(launch(args, argv))  # (before torch is imported or HIP is touched: the rank processes are fresh children)
-    # The contract is ONE JSON line on stdout.  RCCL prints a version banner to the process's stdout when a communicator is
-    # created, so everything else this process (and the libraries under it) writes to fd 1 goes to stderr instead.
+    # ONE JSON line on stdout: RCCL prints a banner to fd 1 when a communicator is created, so everything else goes to stderr.
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
@@ -394,12 +257,13 @@ def main(argv=None):
     if not standin:
         import torch  # first: its bundled HIP runtime is the one this process uses
 
-        if not os.path.exists(os.path.join(ROOT, "crdmodel_amd", "libcrd.so")) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
+        lib = os.path.join(ROOT, "crdmodel_amd", "libcrd.so")
+        if not os.path.exists(lib) and int(os.environ.get("LOCAL_RANK", "0")) == 0:
             from crdmodel_amd.build import build  # a checkout without the (untracked) built library: build it in-tree first
 
             build()
         for _ in range(600):  # the other local ranks wait for rank 0's build
-            if os.path.exists(os.path.join(ROOT, "crdmodel_amd", "libcrd.so")):
+            if os.path.exists(lib):
                 break
             time.sleep(0.5)
     crd = importlib.import_module(args.crd_module)
@@ -407,37 +271,50 @@ def main(argv=None):
     def emit(line):
         os.write(json_fd, (line + "\n").encode())
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank, local_rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if not standin and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: libcrd has no CPU fallback")
     if args.transport == "local" and args.gpus > 1:
         if world != 1:
             raise SystemExit("--transport local is ONE process for all GPUs: start it without a launcher")
-        ndev = 0
-        if not standin:
-            if not torch.cuda.is_available():
-                raise SystemExit("bench.py needs a GPU: libcrd has no CPU fallback")
-            ndev = torch.cuda.device_count()
-        return run_local(args, crd, ndev, emit)
+        return run_local(args, crd, 0 if standin else torch.cuda.device_count(), emit)
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if standin:
-        return run(args, crd, world, rank, local_rank, lambda: None, emit)
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a GPU: libcrd has no CPU fallback")
+        return run(args, crd, world, rank, local_rank, lambda: None, emit, t_start)
     local_rank %= max(1, torch.cuda.device_count())  # a launcher that narrows the visible devices per rank leaves one
     torch.cuda.set_device(local_rank)
-    run(args, crd, world, rank, local_rank, torch.cuda.synchronize, emit)
+    run(args, crd, world, rank, local_rank, torch.cuda.synchronize, emit, t_start)
 
 
-def build_line(args, crd, world, dt, beta, elapsed, kernel, kernel_ms, launches, pts_launch, device_ms_per_step, plan, comm, preheat, staged, per_rank, kernel_ms_source):
-    """The JSON line (a dict) of a finished run.  elapsed: wall time of the K timed steps (MAX over ranks); kernel_ms: average
-    duration of one launch of the dominant kernel on rank 0, covering pts_launch grid points."""
-    n = args.size
-    real = 8 if args.precision == "f64" else 4
-    fused = launches == 1
-    value = n * n * args.steps / elapsed
-    ms_per_step = elapsed * 1e3 / args.steps
+def problem(args, crd):
+    beta = 1.25 if args.model == "fhn" else 0.4
+    params = crd.make_params(args.model, "torus", args.size, 80.0, 20.0, 0.12, beta, ny=args.size, t_boundary=args.t_boundary, precision=args.precision)
+    dt = args.dt if args.dt > 0 else 0.8 * crd.stable_dt(params)
+    return beta, params, dt, crd.run_config(params, wave_length=0.1, wave_width=0.5, wave_inside=0)
+
+
+def issue_model(geo, kernel_ms):
+    """The timed launch on the vector-issue roof: (vector instructions of one trip of the kernel's steady-state loop, counted in the build's
+    own assembly) x trips of all wavefronts x 4 cycles per wavefront instruction, over the device's SIMDs x clock x the launch's time."""
+    if not geo or not geo.get("loop_valu") or kernel_ms <= 0:
+        return None
+    trips = geo["wavefront_iterations"] / geo["iterations_per_trip"]
+    floor_ms = geo["loop_valu"] * trips * 4.0 / (geo["simds"] * geo["clock_khz"] * 1e3) * 1e3
+    return {"issue_frac": floor_ms / kernel_ms, "issue_floor_ms": floor_ms, "valu_instructions_per_trip": geo["loop_valu"], "iterations_per_trip": geo["iterations_per_trip"],
+            "wavefront_iterations": geo["wavefront_iterations"], "cycles_per_wavefront_instruction": 4, "simds": geo["simds"], "clock_mhz": geo["clock_khz"] / 1e3,
+            "vgprs": geo["vgprs"], "wavefronts_per_simd": geo["wavefronts_per_simd"], "lanes_valid": "%d of %d" % (geo["lanes_valid"], geo["lanes"]),
+            "chunk_rows": geo["chunk_rows"], "fill_iterations_per_item": geo["fill_iterations"],
+            "source": "crd_get_launch_geometry: loop instruction mix from the assembly of this build's kernel (tools/kernel_regs.py), launch geometry of this run's plan, "
+                      "hipDeviceProp_t clock; an upper bound on the clock makes it a LOWER bound on the fraction"}
+
+
+def build_line(args, crd, world, dt, beta, elapsed, kernel, kernel_ms, launches, pts_launch, device_ms_per_step, plan, comm, preheat, staged, per_rank, kernel_ms_source,
+               per_launch=None, geometry=None):
+    """The JSON line (a dict) of a finished run.  elapsed: wall time of the K timed steps (MAX over ranks); kernel_ms: average duration
+    of one launch of the dominant kernel on rank 0, covering pts_launch grid points and advancing them per_launch steps."""
+    n, real, fused = args.size, 8 if args.precision == "f64" else 4, launches == 1
+    value, ms_per_step = n * n * args.steps / elapsed, elapsed * 1e3 / args.steps
 
     def rate(nbytes, ms):
         return nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
@@ -445,145 +322,86 @@ def build_line(args, crd, world, dt, beta, elapsed, kernel, kernel_ms, launches,
     if args.launch_plan:
         plan["pinned"] = True  # (--launch-plan: nothing was measured in this run)
     key = crd.plan_key(args.model, args.precision, plan) if fused else "stage23/%s/%s" % (args.model, args.precision)
+    per_launch = (per_launch or int(plan.get("steps_per_launch", 1))) if fused else 1  # steps the TIMED launches advanced (crd_step_timing)
     traffic, traffic_source = measured_traffic(key, pts_launch)
     if fused:
-        # The one-launch step keeps the four stages on chip: the bytes it has to move are one read and one write of the
-        # state, 4 reals per point.  SURVEY 8(d)'s 32 reals per grid-point-step describe a stage-fused RK4 WITHOUT temporal
-        # blocking, i.e. the staged stepper: that figure is reported under survey_8d_equivalent (and measured under `staged`).
         reals_launch = 4
-        bytes_model = ("fused step kernel (all four RK4 stages of a step in one launch): algorithmic bytes per launch = read + "
-                       "write of both fields once = 4 reals per point (%d B) x the points the launch covers" % (4 * real))
+        bytes_model = ("fused step kernel (all RK4 stages of a step in one launch): compulsory bytes per launch = read + write of both fields once = 4 reals per "
+                       "point (%d B) x the points the launch covers%s" % (4 * real, "; this launch advances its points by TWO steps (%d B per grid-point-step)" % (2 * real) if per_launch == 2 else ""))
     else:
         reals_launch = REALS_PER_POINT_STAGE23
-        bytes_model = ("stage-2/3 kernel of the staged stepper: reads y_stage, y_n, acc and writes acc, y_next = 10 reals per "
-                       "point (%d B), SURVEY 8(d); a whole step is 6 + 10 + 10 + 6 = 32 reals per point" % (REALS_PER_POINT_STAGE23 * real))
+        bytes_model = ("stage-2/3 kernel of the staged stepper: reads y_stage, y_n, acc and writes acc, y_next = 10 reals per point (%d B), SURVEY 8(d); a whole "
+                       "step is 6 + 10 + 10 + 6 = 32 reals per point" % (REALS_PER_POINT_STAGE23 * real))
     alg_bytes = reals_launch * real * pts_launch
     achieved = rate(alg_bytes, kernel_ms)
-    # The same accounting on the clock the VALUE is computed from: the algorithmic bytes of ONE STEP of the whole grid (fused: 4 reals
-    # per point; staged: 32) over the wall time per step, per GPU -- what is left of `frac` once launch gaps, exchanges and the
-    # host are paid for.
-    per_launch = int(plan.get("steps_per_launch", 1)) if fused else 1  # (a two-step launch moves its 4 reals per point once per TWO steps)
+    # the same accounting on the clock `value` uses: the compulsory bytes of ONE STEP of the whole grid over the wall time per step, per GPU
     step_bytes = (4.0 / per_launch if fused else REALS_PER_POINT_STEP) * real * n * n
     achieved_wall = rate(step_bytes, ms_per_step) / world
-    stats = committed_json("plan_stats.json").get(key)
-    roofline = {
-        "bound": "hbm",
-        "kernel": kernel,
-        "achieved": achieved,
-        "peak": HBM_PEAK_GBS,
-        "unit": "GB/s",
-        "frac": achieved / HBM_PEAK_GBS,
-        "frac_wall": achieved_wall / HBM_PEAK_GBS,
-        "achieved_wall": achieved_wall,
-        "traffic": traffic,
-        "traffic_source": traffic_source,
-        "bytes_model": bytes_model,
-        "algorithmic_bytes_per_launch": alg_bytes,
-        "kernel_ms": kernel_ms,
-        "kernel_ms_source": kernel_ms_source,
-        "launches_per_step": launches,
-        "device_ms_per_step": device_ms_per_step,
-        "plan_key": key,
-    }
-    busy = committed_json("valu_busy.json").get("%s/%s/cols%d/steps%d" % (args.model, args.precision, int(plan.get("columns_per_lane", 1)), per_launch)) if fused else None
-    if busy:  # what bounds this kernel when it is not HBM: committed SQ counters of the same instantiation
-        roofline["issue"] = busy
-    if stats:  # the committed `rocprofv3 --kernel-trace --stats` record of THIS plan (bench.py --launch-plan pinned), for comparison with kernel_ms
-        roofline["rocprof_stats"] = stats
-    # context for `frac`: what streaming costs on this device at all (committed measurement, not re-measured by this run)
     streams = committed_json("hbm_streams.json")
+    issue = issue_model(geometry, kernel_ms) if fused else None
+    # which roof the launch sits closer to: its compulsory traffic against what this device streams at all (committed measurement; the
+    # spec peak is never reached), its vector issue against the SIMDs' issue rate
+    stream_gbs = 0.5 * (streams.get("read_only_gbs", 0) + streams.get("write_only_gbs", streams.get("read_only_gbs", 0))) if streams else 0.0
+    hbm_of_streaming = achieved / stream_gbs if stream_gbs else achieved / HBM_PEAK_GBS
+    bound = "valu-issue" if issue and issue["issue_frac"] > hbm_of_streaming else "hbm"
+    roofline = {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_wall": achieved_wall / HBM_PEAK_GBS,
+                "achieved_wall": achieved_wall, "traffic": traffic, "traffic_source": traffic_source, "bytes_model": bytes_model, "algorithmic_bytes_per_launch": alg_bytes,
+                "kernel_ms": kernel_ms, "kernel_ms_source": kernel_ms_source, "launches_per_step": launches, "device_ms_per_step": device_ms_per_step, "plan_key": key,
+                "frac_of_device_streaming": hbm_of_streaming if stream_gbs else None}
+    if issue:
+        roofline.update({"issue_frac": issue["issue_frac"], "issue": issue})
+        roofline["bound_note"] = ("`bound` = the roof the launch sits closer to: frac_of_device_streaming (compulsory bytes over what this device streams, "
+                                  "profiles/hbm_streams.json) against issue_frac (vector instructions x 4 cycles over the SIMDs' time).  Probe builds of the two-step "
+                                  "kernel (profiles/r05/two_step_memory_path_ab.txt): the launch as a copy takes 0.93 of the full launch's time, its arithmetic alone 0.76")
+        busy = committed_json("valu_busy.json").get("%s/%s/cols%d/steps%d" % (args.model, args.precision, int(plan.get("columns_per_lane", 1)), per_launch))
+        if busy:  # committed SQ counters of the same instantiation, for comparison with issue_frac
+            roofline["issue"]["sq_counters"] = busy
+    stats = committed_json("plan_stats.json").get(key)
+    if stats:  # the committed `rocprofv3 --kernel-trace --stats` record of THIS plan (bench.py --launch-plan pinned)
+        roofline["rocprof_stats"] = stats
     if streams:
         roofline["device_streaming"] = streams
-    if fused and plan.get("nontemporal_stores"):
-        roofline["traffic_note"] = ("the launch plan is the fastest one measured on this device, not the one that moves the fewest bytes: with non-temporal stores of "
-                                    "the new state time does not follow HBM traffic (DESIGN.md, fused stepper; profiles/pmc_traffic.json has every plan)")
     if fused and per_launch == 2:
-        # What the same rate would ask of a kernel that crosses memory once per step (round 3's): more than any streaming kernel
-        # reaches on this device -- the second step on chip is where the rate comes from, and the kernel is now bound by issue.
         roofline["steps_per_launch"] = 2
         roofline["one_step_per_launch_equivalent"] = {"bytes_per_point_step": 4 * real, "achieved": 2.0 * achieved, "frac": 2.0 * achieved / HBM_PEAK_GBS,
                                                       "note": "bytes a one-step-per-launch kernel would have to move for the same work, over this launch's time"}
-        bytes_model += "; this launch advances its points by TWO steps (%d B per grid-point-step)" % (2 * real)
-        roofline["bytes_model"] = bytes_model
-        roofline["bound_note"] = ("this kernel crosses memory once per two steps and is bound by vector issue (roofline.issue.valu_busy), not by HBM: `frac` is its own "
-                                  "compulsory traffic over its launch time; the HBM-bound forms of the same scheme are roofline.one_step_per_launch and `staged`")
     if fused:
-        eq_bytes = REALS_PER_POINT_STEP * real * pts_launch * per_launch
-        roofline["survey_8d_equivalent"] = {
-            "bytes_per_point_step": REALS_PER_POINT_STEP * real,
-            "achieved": rate(eq_bytes, kernel_ms),
-            "frac": rate(eq_bytes, kernel_ms) / HBM_PEAK_GBS,
-            "note": "staged-scheme traffic the same work would need (32 reals per grid-point-step); > peak because the launch does "
-                    "not move those bytes -- not a bandwidth",
-        }
-    staged_rec = None
+        eq = rate(REALS_PER_POINT_STEP * real * pts_launch * per_launch, kernel_ms)
+        roofline["survey_8d_equivalent"] = {"bytes_per_point_step": REALS_PER_POINT_STEP * real, "achieved": eq, "frac": eq / HBM_PEAK_GBS,
+                                            "note": "staged-scheme traffic the same work would need (32 reals per grid-point-step); > peak because the launch does not move those bytes"}
+    out = {"metric": "grid-point-steps/sec, %s torus %dx%d RK4" % ("FHN" if args.model == "fhn" else "Goldbeter", n, n), "value": value, "unit": "grid-point-steps/s",
+           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+           "dtype": args.precision, "data": "synthetic (reference initial-condition rule: stable state + perturbed rectangle)",
+           "config": {"workload": "%s_torus_%dx%d_%s_rk4" % (args.model, n, n, args.precision), "dt": dt, "stepper": "fused" if fused else "staged",
+                      "decomposition": "phi-slabs x%d" % world, "L": 80.0, "W": 20.0, "D": 0.12, "beta": beta, "t_boundary": args.t_boundary, "halo": comm, "launch_plan": plan,
+                      "preheat": preheat},
+           "roofline": roofline}
     if staged:
         s_el, s_ms, s_kms, s_kernel, s_pts = staged
-        s_alg = REALS_PER_POINT_STAGE23 * real * s_pts
-        sb = REALS_PER_POINT_STEP * real * n * n
-        staged_rec = {
-            "steps": args.staged_steps,
-            "ms_per_step": s_el * 1e3 / args.staged_steps,
-            "value": n * n * args.staged_steps / s_el,
-            "kernel": s_kernel + " (stage 2)",
-            "kernel_ms": s_kms,
-            "algorithmic_bytes_per_launch": s_alg,
-            "achieved": rate(s_alg, s_kms),
-            "frac": rate(s_alg, s_kms) / HBM_PEAK_GBS,
-            "step_bytes_per_point": REALS_PER_POINT_STEP * real,
-            "step_achieved": rate(sb, s_el * 1e3 / args.staged_steps),
-            "step_frac": rate(sb, s_el * 1e3 / args.staged_steps) / HBM_PEAK_GBS,
-            "note": "SURVEY 8(d) accounting on the stepper it describes: four stage kernels per step, timed in this same process before the main run",
-        }
-    out = {
-        "metric": "grid-point-steps/sec, %s torus %dx%d RK4" % ("FHN" if args.model == "fhn" else "Goldbeter", n, n),
-        "value": value,
-        "unit": "grid-point-steps/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": ms_per_step,
-        "higher_is_better": True,
-        "scaling": "strong",
-        "vs_baseline": None,
-        "dtype": args.precision,
-        "data": "synthetic (reference initial-condition rule: stable state + perturbed rectangle)",
-        "config": {"workload": "%s_torus_%dx%d_%s_rk4" % (args.model, n, n, args.precision), "dt": dt, "stepper": "fused" if fused else "staged",
-                   "decomposition": "phi-slabs x%d" % world, "L": 80.0, "W": 20.0, "D": 0.12, "beta": beta, "t_boundary": args.t_boundary,
-                   "halo": comm, "launch_plan": plan, "preheat": preheat},
-        "roofline": roofline,
-    }
-    if staged_rec:
-        out["staged"] = staged_rec
+        s_alg, sb, s_step = REALS_PER_POINT_STAGE23 * real * s_pts, REALS_PER_POINT_STEP * real * n * n, s_el * 1e3 / args.staged_steps
+        out["staged"] = {"steps": args.staged_steps, "ms_per_step": s_step, "value": n * n * args.staged_steps / s_el, "kernel": s_kernel + " (stage 2)", "kernel_ms": s_kms,
+                         "algorithmic_bytes_per_launch": s_alg, "achieved": rate(s_alg, s_kms), "frac": rate(s_alg, s_kms) / HBM_PEAK_GBS,
+                         "step_bytes_per_point": REALS_PER_POINT_STEP * real, "step_achieved": rate(sb, s_step), "step_frac": rate(sb, s_step) / HBM_PEAK_GBS,
+                         "note": "SURVEY 8(d) accounting on the stepper it describes: four stage kernels per step, timed in this same process before the main run"}
     if per_rank:
         out["per_rank"] = per_rank
-        out["per_rank_note"] = ("kernel_ms / ms_per_step / device_ms_per_step: each rank's own figures from the timed region; exposed_halo_ms: "
-                                "average time its compute stream stood at the wait for a halo, per exchange, and exchange_ms: average duration of "
-                                "an exchange on the second stream -- both from a %d-step diagnostic pass after the timed region" % per_rank[0].get("diag_steps", 0))
     return out
 
 
 def run_local(args, crd, ndev, emit):
-    """--transport local: every slab of the N-GPU run in THIS process as a LOCAL group (crd_comm_attach_local), slab k on device k:
-    halos are device-to-device peer copies, the group is stepped by crd_group_step_rk4 with one issuing host thread per device.  No
-    per-launch events in a group call: the kernel time of the roofline is the wall time per step (it includes the exchanges)."""
+    """LOCAL LEG: every slab of the N-GPU run in THIS process as a LOCAL group (crd_comm_attach_local), slab k on device k: halos are
+    device-to-device peer copies, one issuing host thread per device (crd_group_step_rk4_timed: event pairs on every slab's stream)."""
     n, world = args.size, args.gpus
     devices = [int(v) for v in args.devices.split(",")] if args.devices else list(range(world))
     if len(devices) != world or (ndev and max(devices) >= ndev):
         raise SystemExit("--transport local --gpus %d: need %d device ordinals below %d (--devices)" % (world, world, ndev))
-    beta = 1.25 if args.model == "fhn" else 0.4
-    params = crd.make_params(args.model, "torus", n, 80.0, 20.0, 0.12, beta, ny=n, t_boundary=args.t_boundary, precision=args.precision)
-    dt = args.dt if args.dt > 0 else 0.8 * crd.stable_dt(params)
-    cfg = crd.run_config(params, wave_length=0.1, wave_width=0.5, wave_inside=0)
+    beta, params, dt, cfg = problem(args, crd)
     grp = crd.LocalGroup(params, world, devices=devices)
     try:
         grp.set_stepper(args.stepper)
         if args.issuing_threads and hasattr(grp, "set_threads"):
             grp.set_threads(args.issuing_threads)
-        # (no rehearsal in this leg: the longer exchange period where the slabs are tall enough for its 64-row bands -- on the self-ring it
-        # measured 48 against 52 us per step on a rank's share of this grid)
-        period = args.exchange_period or (16 if min(s.nyl for s in grp.slabs) >= 256 else 8)
-        grp.set_exchange_period(period)
+        grp.set_exchange_period(args.exchange_period or (16 if min(s.nyl for s in grp.slabs) >= 256 else 8))
         grp.upload(crd.initial_conditions(cfg))
         for s in grp.slabs:
             if args.launch_plan:
@@ -599,111 +417,66 @@ def run_local(args, crd, ndev, emit):
             preheat.update({"steps": 8 + n_pre, "ms": (time.perf_counter() - t0) * 1e3})
         grp.step_rk4(0.0, dt, args.warmup)  # (returns when every slab's last step is done)
         t0 = time.perf_counter()
-        grp.step_rk4(args.warmup * dt, dt, args.steps)
+        timings = grp.step_rk4_timed(args.warmup * dt, dt, args.steps)  # one dict per slab (crd_step_timing)
         elapsed = time.perf_counter() - t0
         peak = max(s.max_abs() for s in grp.slabs)
         if not (np.isfinite(peak) and peak <= 1e3):
             raise SystemExit("solution blew up (max|u| = %r): dt too large?" % peak)
-        lead = grp.slabs[0]
+        lead, tm0 = grp.slabs[0], timings[0]
         fused = lead.dominant_kernel().startswith("crd_rk4_fused")
-        comm = {"transport": "local", "rccl_comm_count": None, "control_plane": None, "devices": devices,
-                "exchange_period": {"steps": lead.exchange_period()} if fused else None,
-                "issuing_threads": args.issuing_threads or "one per device (crd_group_step_rk4)"}
-        out = build_line(args, crd, world, dt, beta, elapsed, kernel=lead.dominant_kernel(), kernel_ms=elapsed * 1e3 / args.steps / (1 if fused else 4),
-                         launches=1 if fused else 2, pts_launch=n * lead.nyl, device_ms_per_step=None, plan=lead.launch_plan(), comm=comm, preheat=preheat,
-                         staged=None, per_rank=[{"rank": k, "rows": s.nyl, "device": devices[k], "launch_plan": s.launch_plan()} for k, s in enumerate(grp.slabs)],
-                         kernel_ms_source="wall clock per step of the whole group (LOCAL transport: no per-launch events; exchanges and launch gaps included)")
-        out.pop("per_rank_note", None)
-        emit(json.dumps(out))
+        plan = lead.launch_plan()
+        if tm0["kernel_ms"] > 0:
+            kernel_ms, per_launch, pts = tm0["kernel_ms"], tm0.get("timed_steps_per_launch") or 1, n * lead.dominant_kernel_rows()
+            source = "HIP events around one full-height launch on slab 0's compute stream inside the timed region (crd_group_step_rk4_timed)"
+        else:  # nothing timed (a run shorter than an exchange cycle): the wall time of a LAUNCH, exchanges and gaps included
+            per_launch = int(plan.get("steps_per_launch", 1)) if fused else 1
+            kernel_ms, pts = elapsed * 1e3 / args.steps * per_launch / (1 if fused else 4), n * lead.nyl
+            source = "wall clock per launch of the whole group (no launch of this short run was event-timed; exchanges and launch gaps included)"
+        comm = {"transport": "local", "rccl_comm_count": None, "control_plane": None, "devices": devices, "exchange_period": {"steps": lead.exchange_period()} if fused else None,
+                "issuing_threads": args.issuing_threads or "one per device (crd_group_step_rk4_timed)"}
+        per_rank = [{"rank": k, "rows": s.nyl, "device": devices[k], "kernel_ms": timings[k]["kernel_ms"], "device_ms_per_step": timings[k]["ms_total"] / args.steps,
+                     "launch_plan": s.launch_plan()} for k, s in enumerate(grp.slabs)]
+        geometry = lead.launch_geometry() if fused and hasattr(lead, "launch_geometry") else None
+        emit(json.dumps(build_line(args, crd, world, dt, beta, elapsed, kernel=lead.dominant_kernel(), kernel_ms=kernel_ms, launches=1 if fused else 2, pts_launch=pts,
+                                   device_ms_per_step=max(t["ms_total"] for t in timings) / args.steps, plan=plan, comm=comm, preheat=preheat, staged=None, per_rank=per_rank,
+                                   kernel_ms_source=source, per_launch=per_launch, geometry=geometry)))
     finally:
         grp.close()
 
 
-def ring_failed(args, ctl, slab, rank, world, failures, stuck, emit):
-    """The ring did not come up on some rank (every rank knows: the statuses went over the control plane).  Started by bench.py's own
-    launcher, or with --transport rccl: leave with status 4 -- the launcher runs the LOCAL leg / the caller asked for this transport.
-    Started by somebody else's launcher (torch.distributed.run) with --transport auto: the run is not lost -- ranks 1.. leave with status 0,
-    rank 0 starts the LOCAL leg as a CHILD process (one process for all GPUs; nothing that has touched the GPU is replaced), passes its
-    line on with the reason in config.launcher and leaves with the child's status.  A rank whose bring-up thread is stuck inside RCCL
-    cannot tear anything down: it leaves through os._exit."""
-    import subprocess
-
-    why = "; ".join(failures)
-    relay = args.transport == "auto" and not os.environ.get("CRD_BENCH_SELF_LAUNCHED")
-    code = 4
-    if relay and rank == 0:
-        sys.stderr.write("bench.py: the rccl leg failed (%s); rank 0 runs the LOCAL leg in a child process\n" % why)
-    if not stuck:
-        slab.close()
-    ctl.close()
-    if relay:
-        code = 0
-        if rank == 0:
-            argv = [a for a in sys.argv[1:]]
-            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "GROUP_RANK", "ROLE_RANK", "MASTER_ADDR", "MASTER_PORT",
-                                                                     "TORCHELASTIC_RUN_ID", "GLOO_SOCKET_IFNAME")}
-            line, code = None, 1
-            try:
-                r = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--transport", "local"], env=env, stdout=subprocess.PIPE, text=True,
-                                   timeout=args.launch_timeout_s)
-                line, code = last_json_line(r.stdout), r.returncode
-            except subprocess.TimeoutExpired:
-                why += "; local: did not finish within %.0f s" % args.launch_timeout_s
-            if line is not None:
-                line.setdefault("config", {})["launcher"] = {"mode": "%d rank processes started by an external launcher; the ring failed, rank 0 ran the LOCAL leg in a child process" % world,
-                                                              "transports_tried": ["rccl", "local"], "fallback_reasons": ["rccl: " + why]}
-                emit(json.dumps(line))
-            else:
-                sys.stderr.write("bench.py: no leg produced a result (rccl: %s)\n" % why)
-                code = code or 1
-    elif rank == 0:
-        sys.stderr.write("bench.py: set-up of the ring failed: %s\n" % why)
-    sys.stdout.flush()
-    sys.stderr.flush()
-    os._exit(code) if stuck else sys.exit(code)
-
-
-def run(args, crd, world, rank, local_rank, device_sync, emit):
-    """The benchmark proper, on top of the `crd` API (crdmodel_amd; tests/test_distributed_cpu.py drives this very function with
-    2 and 3 processes over gloo against a stand-in that keeps its planes in numpy and moves its halos with the library's own
-    ring plan -- the N > 1 control flow, the self-check across real ranks, the slack decision, the per-rank gather and the JSON
-    line are thereby exercised before the first run on more than one GPU).  device_sync(): wait for the device; emit(line)."""
+def run(args, crd, world, rank, local_rank, device_sync, emit, t_start=None):
+    """RANK: the benchmark proper on top of the `crd` API (tests/test_distributed_cpu.py drives this very function with 2, 3 and 8
+    processes over gloo against a stand-in whose halos travel by the library's own ring plan).  device_sync(): wait for the device."""
+    t_start = time.monotonic() if t_start is None else t_start
     ctl = ControlPlane(world, rank)
-
     n = args.size
-    beta = 1.25 if args.model == "fhn" else 0.4
-    params = crd.make_params(args.model, "torus", n, 80.0, 20.0, 0.12, beta, ny=n, t_boundary=args.t_boundary, precision=args.precision)
-    dt = args.dt if args.dt > 0 else 0.8 * crd.stable_dt(params)
-    cfg = crd.run_config(params, wave_length=0.1, wave_width=0.5, wave_inside=0)
-
+    beta, params, dt, cfg = problem(args, crd)
     slab = None
 
     def bail(msg):
-        """Leave with a non-zero status from a clean state: every rank takes the same exit, the context and the process group are
-        torn down first (a process that has touched the GPU is never replaced with exec)."""
+        """Leave with a non-zero status from a clean state: every rank takes the same exit, context and process group torn down first."""
         if slab is not None:
             slab.close()
         ctl.close()
         raise SystemExit(msg)
 
-    # Every rank reports whether its own set-up worked BEFORE anybody enters a collective of the ring: a rank that failed alone
-    # (no device memory, RCCL library missing) would otherwise leave the others waiting inside ncclCommInitRank.
-    problem = ""
-    try:
-        slab = crd.Slab(params, rank, world, local_rank)
-        ident = crd.rccl_unique_id() if (rank == 0 and (world > 1 or args.force_rccl)) else b""
-    except Exception as e:  # noqa: BLE001 -- reported through the control plane, then every rank leaves
-        problem, ident = "rank %d: %s" % (rank, e), b""
-    failed = [p for p in ctl.gather(problem) if p]
-    if failed:
-        bail("set-up failed: " + "; ".join(failed))
-    # Bringing the ring up -- ncclCommInitRank, what the communicator says about itself, one exchange checked row by row -- happens in a
-    # helper thread, BEFORE anything is timed: a ring that hangs at first contact cannot be interrupted from Python, but the main thread
-    # can stop waiting for it (--ring-timeout-s).  Every rank then says over the control plane how it went, and all take the same way on.
     def fence():
         ctl.barrier()
         device_sync()
 
+    # ROLL CALL: every rank reports whether its own set-up worked BEFORE anybody enters a collective of the ring -- a rank that failed
+    # alone (no device memory, RCCL library missing) would otherwise leave the others waiting inside ncclCommInitRank.
+    trouble = ""
+    try:
+        slab = crd.Slab(params, rank, world, local_rank)
+        ident = crd.rccl_unique_id() if (rank == 0 and (world > 1 or args.force_rccl)) else b""
+    except Exception as e:  # noqa: BLE001 -- reported through the control plane, then every rank leaves
+        trouble, ident = "rank %d: %s" % (rank, e), b""
+    failed = [p for p in ctl.gather(trouble) if p]
+    if failed:
+        bail("set-up failed: " + "; ".join(failed))
+    # RING BRING-UP in a helper thread, before anything is timed: a ring that hangs at first contact cannot be interrupted from Python,
+    # but the main thread can stop waiting for it.  Then the AGREED OUTCOME over the control plane: all take the same way on.
     ring_wanted = world > 1 or args.force_rccl
     ident = ctl.broadcast_bytes(ident, 128) if world > 1 else ident
     up = {"status": "ok", "bad": 0, "info": None}
@@ -719,33 +492,31 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
         except Exception as e:  # noqa: BLE001 -- reported through the control plane
             up["status"] = "rank %d: %s" % (rank, e)
 
+    stuck = False
     if ring_wanted:
         import threading
 
         th = threading.Thread(target=bring_ring_up, daemon=True)
         th.start()
         th.join(args.ring_timeout_s if args.ring_timeout_s > 0 else None)
-        if th.is_alive():
+        stuck = th.is_alive()
+        if stuck:
             up["status"] = "rank %d: the RCCL ring did not come up within %.0f s (communicator set-up / first exchange)" % (rank, args.ring_timeout_s)
             sys.stderr.write("bench.py: %s\n" % up["status"])
             sys.stderr.flush()
     else:
         bring_ring_up()
-    stuck = ring_wanted and th.is_alive()
     failures = [st for st in ctl.gather(up["status"]) if st != "ok"]
     if failures:
-        ring_failed(args, ctl, slab, rank, world, failures, stuck, emit)  # does not return
+        ring_failed(args, ctl, slab, rank, world, failures, stuck, emit, t_start)  # does not return
     slab.set_stepper(args.stepper)
     transport, comm_ranks, comm_rank = up["info"]
     comm = {"transport": transport, "rccl_comm_count": comm_ranks if transport == "rccl" else None, "control_plane": "gloo" if world > 1 else None}
     if transport == "rccl" and os.environ.get("CRD_RCCL_LIBRARY"):
-        # not librccl: e.g. the tests' shared-memory stand-in that lets several rank processes share one GPU -- a rehearsal of the
-        # N-rank control flow, never a performance figure
-        comm["rccl_library_override"] = os.environ["CRD_RCCL_LIBRARY"]
+        comm["rccl_library_override"] = os.environ["CRD_RCCL_LIBRARY"]  # not librccl (the tests' shared-memory stand-in): a rehearsal of the control flow, never a figure
     if transport == "rccl":
-        depth = up["depth"]
         bad_total, wrong_count, wrong_rank = ctl.sum_ints([up["bad"], int(comm_ranks != world), int(comm_rank != rank)])
-        comm["halo_selfcheck"] = {"depth": depth, "fields": 2, "ghost_rows_checked_per_rank": 4 * depth, "mismatching_values": bad_total,
+        comm["halo_selfcheck"] = {"depth": up["depth"], "fields": 2, "ghost_rows_checked_per_rank": 4 * up["depth"], "mismatching_values": bad_total,
                                   "ok": bad_total == 0 and wrong_count == 0 and wrong_rank == 0}
         if not comm["halo_selfcheck"]["ok"]:
             bail("halo self-check failed: %d ghost values differ from the neighbours' rows; %d ranks see a communicator of the wrong size, %d the wrong rank"
@@ -753,8 +524,7 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
     y_init = crd.initial_conditions(cfg, slab.js, slab.je)
     slab.upload(y_init)
 
-    # Beside a fused run: the staged stepper (four stage kernels per step -- the scheme SURVEY 8(d)'s 256 B per grid-point-step
-    # describes) timed in the same process on the same state, so that its roofline fraction is a driver-timed number too.
+    # Beside a fused run (N = 1): the staged stepper -- the scheme SURVEY 8(d)'s 256 B per grid-point-step describes -- in the same process.
     staged = None
     will_fuse = args.stepper != "staged" and slab.dominant_kernel().startswith("crd_rk4_fused")
     if world == 1 and will_fuse and args.staged_steps > 0:
@@ -764,8 +534,7 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
         t0 = time.perf_counter()
         s_ms, s_kms, _ = slab.step_rk4_timed(4 * dt, dt, args.staged_steps)
         fence()
-        s_el = time.perf_counter() - t0
-        staged = (s_el, s_ms, s_kms, slab.dominant_kernel(), n * slab.dominant_kernel_rows())
+        staged = (time.perf_counter() - t0, s_ms, s_kms, slab.dominant_kernel(), n * slab.dominant_kernel_rows())
         slab.set_stepper(args.stepper)
         slab.upload(y_init)
     if args.launch_plan:
@@ -774,10 +543,10 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
     slab.plan_launches()  # the launch plan is measured here, outside every timed region (also with --warmup 0)
     t_plan = time.perf_counter() - t_plan
 
-    # Rehearsal (ring runs with the one-launch stepper): three exchange cycles with per-exchange event pairs.  If on ANY rank the
-    # compute stream stood at its wait for a halo for more than a queue latency's worth, the exchange does not land within the two
-    # sweeps it is given on this machine: every rank then gives it a third (crd_set_halo_slack: one more small launch per cycle,
-    # same bits).  The choice and what the rehearsal measured go into config.halo.slack; the state is uploaded afresh afterwards.
+    # REHEARSALS (ring runs with the one-launch stepper).  Slack: three exchange cycles with per-exchange event pairs; if on ANY rank the
+    # compute stream stood at its wait for a halo for longer than a queue latency, every rank gives the exchange a third sweep of cover
+    # (crd_set_halo_slack; same bits).  Period: 8 and 16 steps per exchange stepped for four cycles of the longer one, twice; the faster
+    # (MAX over ranks of each rank's best) is kept if it wins by > 1 %.  Both go to the top level of config.halo.
     if transport == "rccl" and will_fuse:
         def rehearse():
             slab.set_diagnostics(True)
@@ -786,17 +555,12 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
             slab.set_diagnostics(False)
             return ctl.max_float(tm["exposed_halo_ms"] / max(1, tm["halo_waits"]))
 
-        exposed = [rehearse()]
-        sweeps = 1
+        exposed, sweeps = [rehearse()], 1
         if exposed[0] > args.halo_slack_threshold_ms:
             sweeps = 2
             slab.set_halo_slack(2)
             exposed.append(rehearse())
         comm["slack"] = {"sweeps": sweeps, "threshold_ms": args.halo_slack_threshold_ms, "rehearsal_exposed_halo_ms_max_over_ranks": exposed}
-        # ... and the exchange period (crd_set_exchange_period: E fused steps per deep-halo exchange of 4 E rows).  8 is the default; 16
-        # halves what a cycle costs per step beside its sweeps -- two small launches, two cross-stream waits, the exchange's latency --
-        # for a few per cent more redundantly recomputed ghost rows.  Which wins depends on the link: both are stepped for four cycles
-        # of the longer period, twice, on every rank, and the faster (MAX over ranks of each rank's best) is kept if it wins by > 1 %.
         period = {"steps": slab.exchange_period(), "chosen_by": "default"}
         if args.exchange_period:
             slab.set_exchange_period(args.exchange_period)
@@ -806,8 +570,7 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
             for e in (8, 16):
                 slab.set_exchange_period(e)
                 slab.step_rk4_timed(0.0, dt, 2 * e)  # (settle into the cycle)
-                best = min(slab.step_rk4_timed(0.0, dt, 64)[0] / 64 for _ in range(2))
-                trial[e] = ctl.max_float(best)
+                trial[e] = ctl.max_float(min(slab.step_rk4_timed(0.0, dt, 64)[0] / 64 for _ in range(2)))
             keep = 16 if trial[16] < 0.99 * trial[8] else 8
             slab.set_exchange_period(keep)
             period = {"steps": keep, "chosen_by": "rehearsal", "rehearsal_device_ms_per_step_max_over_ranks": {str(k): v for k, v in trial.items()}}
@@ -815,10 +578,8 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
         slab.upload(y_init)
     del y_init
 
-    # Pre-heat: the timed region may be as short as 20 steps (8 ms at 8192^2), and behind an upload the device has been idle: the
-    # same 20 steps measured 5 % slower behind 5 warm-up steps than behind 800 (profiles/r03/warm_clocks.txt).  So a few hundred
-    # milliseconds of untimed stepping come first, then the W warm-up steps, then the K timed ones, back to back.  Stepping is
-    # collective in a multi-rank run: the count is the MAX over the ranks' estimates.
+    # Pre-heat (the same 20 steps measured 5 % slower behind 5 warm-up steps than behind 800: profiles/r03/warm_clocks.txt), warm-up, then
+    # the timed region: barrier + device synchronisation, K steps, device synchronisation, time stamp, barrier; MAX over the ranks.
     preheat = {"ms_requested": args.preheat_ms, "steps": 0}
     if args.preheat_ms > 0:
         t0 = time.perf_counter()
@@ -828,10 +589,6 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
         slab.step_rk4(0.0, dt, n_pre, sync=True)
         preheat.update({"steps": 8 + n_pre, "ms": (time.perf_counter() - t0) * 1e3})
     slab.step_rk4(0.0, dt, args.warmup, sync=True)
-    # The timed region: barrier + device synchronisation, K steps, device synchronisation (step_rk4_timed returns when this
-    # rank's last step is done), time stamp, barrier; the figure reported is the MAX over the ranks.  The closing barrier sits
-    # behind the time stamp: over gloo it is tens of microseconds of host round trips that are no part of a step (the ranks
-    # are coupled through their halos anyway: nobody finishes much before the slowest).
     fence()
     t0 = time.perf_counter()
     ms_dev, kernel_ms, launches = slab.step_rk4_timed(args.warmup * dt, dt, args.steps)
@@ -839,9 +596,8 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
     elapsed_rank = time.perf_counter() - t0
     ctl.barrier()
     elapsed = ctl.max_float(elapsed_rank)
-    # The same K steps again, a few times (each between the same fences, MAX over ranks): the spread of the figure on this box, this
-    # run.  Reported beside `value`, never in it.
-    spread = []
+    timed = slab.step_timing()
+    spread = []  # the same K steps again, a few times, same fences: the spread of the figure on this box (never part of `value`)
     for r in range(max(0, args.repeats)):
         fence()
         t0 = time.perf_counter()
@@ -849,8 +605,8 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
         device_sync()
         spread.append(ctl.max_float(time.perf_counter() - t0) * 1e3 / args.steps)
     plan_used = dict(slab.launch_plan(), measured_in_s=round(t_plan, 3))
-    # Beside a two-steps-per-launch run (N = 1): the one-step-per-launch kernel -- round 3's, bound by HBM -- timed in this same process,
-    # so that the line carries an HBM-roof figure of the fused design from the same box next to the issue-bound kernel's.
+    geometry = slab.launch_geometry() if will_fuse and hasattr(slab, "launch_geometry") else None
+    # Beside a two-steps-per-launch run (N = 1): the one-step-per-launch kernel, which crosses memory once per step, in this same process.
     one_step = None
     if world == 1 and will_fuse and plan_used.get("steps_per_launch") == 2 and not args.launch_plan and args.one_step_steps > 0:
         slab.set_launch_plan(0, plan_used["xcd_mapping"], plan_used["columns_per_lane"], 1, 1)
@@ -862,8 +618,7 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
     if blown:
         bail("solution blew up on %d rank(s) (this rank: max|u| = %r): dt too large?" % (blown, peak))
 
-    # Per-rank diagnostics (multi-rank runs and the self-ring rehearsal): the timed region's own figures, then a short pass with
-    # per-exchange event pairs switched on -- three exchange cycles, outside the rate.
+    # Per-rank figures (ring runs): the timed region's own, then a short pass with per-exchange event pairs -- three cycles, outside the rate.
     per_rank = None
     if transport == "rccl":
         rec = {"rank": rank, "rows": slab.nyl, "kernel_ms": kernel_ms, "kernel_rows": slab.dominant_kernel_rows(), "ms_per_step": elapsed_rank * 1e3 / args.steps,
@@ -877,26 +632,30 @@ def run(args, crd, world, rank, local_rank, device_sync, emit):
                     "exposed_halo_ms": tm["exposed_halo_ms"] / max(1, tm["halo_waits"]), "exchange_ms": tm["exchange_ms"] / max(1, tm["exchanges"]),
                     "halo_slack": tm["halo_slack"], "agreement_restarts": tm["agreement_restarts"]})
         per_rank = ctl.gather(rec)
+        # did RCCL see N ranks, and did the exchange hide?  At a glance, at the top level of config.halo:
+        comm["exposed_halo_ms_per_rank"] = [q["exposed_halo_ms"] for q in per_rank]
+        comm["exchange_ms_per_rank"] = [q["exchange_ms"] for q in per_rank]
 
     if rank == 0:
         out = build_line(args, crd, world, dt, beta, elapsed, kernel=slab.dominant_kernel(), kernel_ms=kernel_ms, launches=launches,
                          pts_launch=n * (per_rank[0]["kernel_rows"] if per_rank else slab.dominant_kernel_rows()),  # (the rows of the launch the timed region timed)
                          device_ms_per_step=ms_dev / args.steps, plan=plan_used, comm=comm, preheat=preheat, staged=staged, per_rank=per_rank,
-                         kernel_ms_source="HIP events around sampled launches on the library's compute stream inside the timed region")
+                         kernel_ms_source="HIP events around sampled launches on the library's compute stream inside the timed region",
+                         per_launch=timed.get("timed_steps_per_launch") or None, geometry=geometry)
+        if per_rank:
+            out["per_rank_note"] = ("kernel_ms / ms_per_step / device_ms_per_step: each rank's own figures from the timed region; exposed_halo_ms: average time its compute "
+                                    "stream stood at the wait for a halo, per exchange, and exchange_ms: average duration of an exchange on the second stream -- both from a "
+                                    "%d-step diagnostic pass after the timed region" % per_rank[0].get("diag_steps", 0))
         if one_step:
-            real = 8 if args.precision == "f64" else 4
-            o_bytes = 4 * real * n * n
-            out["roofline"]["one_step_per_launch"] = {
-                "kernel_ms": one_step[1], "device_ms_per_step": one_step[0], "steps": args.one_step_steps,
-                "achieved": o_bytes / (one_step[1] * 1e-3) / 1e9, "frac": o_bytes / (one_step[1] * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                "plan_key": crd.plan_key(args.model, args.precision, one_step[2]),
-                "note": "the same grid stepped with ONE step per launch (the HBM-bound kernel of round 3), timed after the main run in this process: "
-                        "read + write of both fields once per step over its launch time"}
+            o_rate = 4 * (8 if args.precision == "f64" else 4) * n * n / (one_step[1] * 1e-3) / 1e9
+            out["roofline"]["one_step_per_launch"] = {"kernel_ms": one_step[1], "device_ms_per_step": one_step[0], "steps": args.one_step_steps, "achieved": o_rate,
+                                                      "frac": o_rate / HBM_PEAK_GBS, "plan_key": crd.plan_key(args.model, args.precision, one_step[2]),
+                                                      "note": "the same grid stepped with ONE step per launch, timed after the main run in this process: read + write of both fields once per step"}
         if spread:
             out["timing_spread"] = {"repeats_ms_per_step": spread, "min": min(spread), "max": max(spread),
                                     "note": "the K timed steps repeated %d times after the timed region, same fences; `value` is the first, timed pass only" % len(spread)}
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args, {"beta": beta}, dt)
+            out["cpu_baseline"] = cpu_baseline(args, beta, dt)
         emit(json.dumps(out))
     slab.close()
     ctl.close()

@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # CRD_LIBRARY points the binding at another build of the same ABI (tuning builds under tools/); default is the in-tree library.
 LIB_PATH = os.environ.get("CRD_LIBRARY") or os.path.join(_PKG, "libcrd.so")
 
-ABI_VERSION = 4  # CRD_ABI_VERSION of include/crd.h (tests/test_host_abi.py keeps the two in step)
+ABI_VERSION = 5  # CRD_ABI_VERSION of include/crd.h (tests/test_host_abi.py keeps the two in step)
 OK, EINVAL, ENOMEM, EHIP, ERCCL, EIO, EPARSE, ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
 MODEL_FHN, MODEL_GOLDBETER = 0, 1
 SURFACE_TORUS, SURFACE_FLAT = 0, 1
@@ -96,11 +96,19 @@ class LaunchPlan(C.Structure):
                 ("ms_chosen", C.c_double)]
 
 
+class LaunchGeometry(C.Structure):
+    """crd_launch_geometry"""
+
+    _fields_ = [(f, C.c_int32) for f in ("rows", "strips", "chunk_rows", "chunks", "workgroups", "wavefronts_per_workgroup", "fill_iterations", "iterations_per_trip",
+                                         "lanes", "lanes_valid", "vgprs", "sgprs", "lds_bytes", "scratch_bytes", "wavefronts_per_simd", "loop_valu", "loop_salu",
+                                         "loop_vmem", "loop_lds", "loop_instructions", "simds", "clock_khz", "reserved")] + [("wavefront_iterations", C.c_int64)]
+
+
 class StepTiming(C.Structure):
     """crd_step_timing"""
 
     _fields_ = [("ms_total", C.c_double), ("kernel_ms", C.c_double), ("exposed_halo_ms", C.c_double), ("exchange_ms", C.c_double),
-                ("steps", C.c_int64), ("halo_slack", C.c_int32), ("reserved", C.c_int32), ("halo_waits", C.c_int32), ("exchanges", C.c_int32),
+                ("steps", C.c_int64), ("halo_slack", C.c_int32), ("timed_steps_per_launch", C.c_int32), ("halo_waits", C.c_int32), ("exchanges", C.c_int32),
                 ("agreement_restarts", C.c_int64)]
 
 
@@ -158,6 +166,7 @@ _SIGNATURES = {
     "crd_group_integrate_adaptive": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.c_double, C.POINTER(AdaptiveOptions),
                                              C.POINTER(AdaptiveStats)]),
     "crd_group_step_rk4": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.c_double, C.c_int64]),
+    "crd_group_step_rk4_timed": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.c_double, C.c_int64]),
     "crd_group_rhs_device": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
     "crd_group_rhs_host": (C.c_int, [C.POINTER(_vp), C.c_int, C.c_double, C.POINTER(_vp), C.POINTER(_vp)]),
     "crd_step_rk4_timed": (C.c_int, [_vp, C.c_double, C.c_double, C.c_int64, C.POINTER(C.c_double),
@@ -169,6 +178,7 @@ _SIGNATURES = {
     "crd_trace_range_pop": (None, []),
     "crd_set_autotune": (C.c_int, [_vp, C.c_int]),
     "crd_get_launch_plan": (C.c_int, [_vp, C.POINTER(LaunchPlan)]),
+    "crd_get_launch_geometry": (C.c_int, [_vp, C.POINTER(LaunchGeometry)]),
     "crd_set_launch_plan": (C.c_int, [_vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "crd_plan_launches": (C.c_int, [_vp]),
     "crd_set_diagnostics": (C.c_int, [_vp, C.c_int]),

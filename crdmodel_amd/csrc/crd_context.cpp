@@ -219,7 +219,7 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	CREATE_TRY(hipMalloc(&c->ghost_hi, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc(&c->edge_lo, (size_t)c->nx * c->real_size));
 	CREATE_TRY(hipMalloc(&c->edge_hi, (size_t)c->nx * c->real_size));
-	CREATE_TRY(hipMalloc((void **)&c->scalar_dev, 2 * sizeof(double)));
+	CREATE_TRY(hipMalloc((void **)&c->scalar_dev, 4 * sizeof(double)));  // [0] reductions, [2], [3] the adaptive integrator's attempt slots
 	CREATE_TRY(hipHostMalloc((void **)&c->scalar_host, 8 * sizeof(double), hipHostMallocPortable | hipHostMallocMapped));
 	if (d0 > 1) {  // theta-blocks: ghost / edge column strips of var0, per stage-input plane and one pair for the AoS RHS
 		const size_t strip = (size_t)c->nyl * c->real_size;
@@ -726,6 +726,52 @@ int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
 	out->steps_per_launch = (c->plan.tuned && c->plan.steps == 2 && fused_two_steps_supported(c->desc)) ? 2 : 1;
 	out->ms_default = c->plan.ms_default;
 	out->ms_chosen = c->plan.ms_best;
+	return CRD_OK;
+}
+
+int crd_get_launch_geometry(crd_ctx *c, crd_launch_geometry *out)
+{
+	if (!c || !out) return CRD_EINVAL;
+	*out = crd_launch_geometry{};
+	if (resolve_stepper(c) != CRD_STEPPER_FUSED) return fail(c, CRD_ESTATE, "launch geometry: this context does not step with the one-launch kernel");
+	if (int rc = set_device(c)) return rc;
+	int64_t rows = c->nyl;
+	if (int rc = crd_dominant_kernel_rows(c, &rows)) return rc;  // (a multi-slab context: the full-height launch of the exchange cycle that the timed calls time)
+	const int ext = (int)(rows - c->nyl) / 2;
+	FusedGeometry g{};
+	FusedCall call{};
+	call.dt = 1.0;
+	call.steps = (c->plan.tuned && c->plan.steps == 2 && fused_two_steps_supported(c->desc)) ? 2 : 1;
+	call.plan = &c->plan;
+	call.geometry = &g;
+	HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
+	out->strips = g.strips;
+	out->chunk_rows = g.chunk_rows;
+	out->chunks = g.chunks;
+	out->workgroups = g.blocks;
+	out->wavefronts_per_workgroup = g.waves_per_block;
+	out->fill_iterations = g.fill_iterations;
+	out->iterations_per_trip = g.iterations_per_trip;
+	out->lanes = g.lanes;
+	out->lanes_valid = g.lanes_valid;
+	out->rows = (int32_t)rows;
+	out->wavefront_iterations = g.wave_iterations;
+	if (const KernelStats *k = step_kernel_stats(g.real_bytes, g.model, g.absorb, g.embed, g.cols, g.nt, g.steps)) {
+		out->vgprs = k->vgprs;
+		out->sgprs = k->sgprs;
+		out->lds_bytes = k->lds_bytes;
+		out->scratch_bytes = k->scratch_bytes;
+		out->wavefronts_per_simd = k->wavefronts_per_simd;
+		out->loop_valu = k->loop_valu;
+		out->loop_salu = k->loop_salu;
+		out->loop_vmem = k->loop_vmem;
+		out->loop_lds = k->loop_lds;
+		out->loop_instructions = k->loop_total;
+	}
+	hipDeviceProp_t prop;
+	HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));
+	out->simds = 4 * prop.multiProcessorCount;
+	out->clock_khz = prop.clockRate;
 	return CRD_OK;
 }
 

@@ -172,6 +172,7 @@ struct crd_ctx {
 	int cycle_pos = -1;
 	int xchg_plane = 0;    // the state plane the exchange in progress sends this context's rows from (LOCAL neighbours pull from it)
 	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
+	int timed_steps = 0;   // steps per launch of the launches the last timed call put its events around (all alike: 1, or 2)
 	int cycle_start = -1;  // the decision for the call in progress, taken for ALL slabs of the run before any thread issues (run_steps)
 	// RCCL runs: the ranks AGREE on the cycle position at the start of every stepping call (one 2-value ncclAllReduce(min) of
 	// (pos, -pos) on the comm stream, overlapped with the call's first step where that step involves no exchange): a rank whose

@@ -459,10 +459,10 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 	    std::make_integer_sequence<int, PRO>{});
 	int m = PRO;
 	for (; m + M - 1 < niter; m += M)  // steady state: M iterations per trip, every register slot a compile-time constant
-		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::false_type{}); }, std::make_integer_sequence<int, M>{});
+		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::integral_constant<int, 4 * kApron>{}); }, std::make_integer_sequence<int, M>{});
 	for_sequence(
 	    [&](auto k) {
-		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::false_type{});
+		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::integral_constant<int, 4 * kApron>{});
 	    },
 	    std::make_integer_sequence<int, M - 1>{});
 	if constexpr (EMBED != 0) {
@@ -650,34 +650,49 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 
 	// Stages 1..4 of one step on the pipeline P whose newest row is `p` (slot S0): new state of row p - 4 in (nu, nv).
 	// flag_bit: where the step's four stage flags start in amask; b4: b(j) of row p - 4 (read by the caller before row p took over its slot).
-	auto stages = [&](Pipe &P, const int p, auto kk, const int flag_bit, const Real b4, V &nu, V &nv) {
+	// `live`: the iterations this pipeline has been fed for (m for the first, m - 8 for the second; 8 and more: all stages run).  In the
+	// chunk's first sixteen iterations stage k has complete inputs only from the pipeline's iteration 2 k on -- the stages before that are
+	// skipped (their rows lie outside what the chunk's outputs depend on: nothing downstream reads what they would have written).  Half
+	// the work of those iterations, which is a tenth of a 61-row item's -- one rank's share of an 8-GPU run -- and a third of an edge band's.
+	auto stages = [&](Pipe &P, const int p, auto kk, auto live_c, const int flag_bit, const Real b4, V &nu, V &nv) {
 		constexpr int K = decltype(kk)::value;
+		constexpr int live = decltype(live_c)::value;  // (compile-time: the sixteen filling iterations are sixteen pieces of straight-line code)
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M, S5 = (K + 2 * M - 5) % M;
 		V du, dv;
-		rhs_lane<V, MODEL>(P.u0[S1], P.u0[S2], P.u0[S0], P.v0[S1], cE, cWn, cP, P.bq[S1], ka4,
-		                       ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), du, dv);
-		P.U1[S1] = fmadd(h2, du, P.u0[S1]);
-		P.V1[S1 & 1] = fmadd(h2, dv, P.v0[S1]);
-		P.aU[S1] = fmadd(h6, du, P.u0[S1]);
-		P.aV[S1] = fmadd(h6, dv, P.v0[S1]);
-		rhs_lane<V, MODEL>(P.U1[S2], P.U1[S3], P.U1[S1], P.V1[S2 & 1], cE, cWn, cP, P.bq[S2], ka4,
-		                       ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), du, dv);
-		P.U2[S2] = fmadd(h2, du, P.u0[S2]);
-		P.V2[S2 & 1] = fmadd(h2, dv, P.v0[S2]);
-		P.aU[S2] = fmadd(h3, du, P.aU[S2]);
-		P.aV[S2] = fmadd(h3, dv, P.aV[S2]);
-		rhs_lane<V, MODEL>(P.U2[S3], P.U2[S4], P.U2[S2], P.V2[S3 & 1], cE, cWn, cP, P.bq[S3], ka4,
-		                       ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), du, dv);
-		P.U3[S3] = fmadd(h1, du, P.u0[S3]);
-		P.V3[S3 & 1] = fmadd(h1, dv, P.v0[S3]);
-		P.aU[S3] = fmadd(h3, du, P.aU[S3]);
-		P.aV[S3] = fmadd(h3, dv, P.aV[S3]);
-		rhs_lane<V, MODEL>(P.U3[S4], P.U3[S5], P.U3[S3], P.V3[S4 & 1], cE, cWn, cP, b4, ka4,
-		                       ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), du, dv);
-		nu = fmadd(h6, du, P.aU[S4]);
-		nv = fmadd(h6, dv, P.aV[S4]);
+		if constexpr (live >= 2) {
+			rhs_lane<V, MODEL>(P.u0[S1], P.u0[S2], P.u0[S0], P.v0[S1], cE, cWn, cP, P.bq[S1], ka4,
+			                       ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), du, dv);
+			P.U1[S1] = fmadd(h2, du, P.u0[S1]);
+			P.V1[S1 & 1] = fmadd(h2, dv, P.v0[S1]);
+			P.aU[S1] = fmadd(h6, du, P.u0[S1]);
+			P.aV[S1] = fmadd(h6, dv, P.v0[S1]);
+		}
+		if constexpr (live >= 4) {
+			rhs_lane<V, MODEL>(P.U1[S2], P.U1[S3], P.U1[S1], P.V1[S2 & 1], cE, cWn, cP, P.bq[S2], ka4,
+			                       ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), du, dv);
+			P.U2[S2] = fmadd(h2, du, P.u0[S2]);
+			P.V2[S2 & 1] = fmadd(h2, dv, P.v0[S2]);
+			P.aU[S2] = fmadd(h3, du, P.aU[S2]);
+			P.aV[S2] = fmadd(h3, dv, P.aV[S2]);
+		}
+		if constexpr (live >= 6) {
+			rhs_lane<V, MODEL>(P.U2[S3], P.U2[S4], P.U2[S2], P.V2[S3 & 1], cE, cWn, cP, P.bq[S3], ka4,
+			                       ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), du, dv);
+			P.U3[S3] = fmadd(h1, du, P.u0[S3]);
+			P.V3[S3 & 1] = fmadd(h1, dv, P.v0[S3]);
+			P.aU[S3] = fmadd(h3, du, P.aU[S3]);
+			P.aV[S3] = fmadd(h3, dv, P.aV[S3]);
+		}
+		nu = nv = zero_v;
+		if constexpr (live >= 8) {
+			rhs_lane<V, MODEL>(P.U3[S4], P.U3[S5], P.U3[S3], P.V3[S4 & 1], cE, cWn, cP, b4, ka4,
+			                       ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), du, dv);
+			nu = fmadd(h6, du, P.aU[S4]);
+			nv = fmadd(h6, dv, P.aV[S4]);
+		}
 	};
-	auto iteration = [&](int m, auto kk) {
+	auto iteration = [&](int m, auto kk, auto fed_c) {
+		constexpr int FED = decltype(fed_c)::value;  // iterations before this one, if fewer than sixteen
 		constexpr int K = decltype(kk)::value;
 		constexpr int S0 = K % M, S4 = (K + 2 * M - 4) % M;
 #if !defined(CRD_NO_LOCKSTEP) && !defined(CRD_NO_LOCKSTEP_TWO)
@@ -702,13 +717,13 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		nu = A.u0[S0] + (V)b4a;
 		nv = A.v0[S0] + (V)b4b;
 #else
-		stages(A, p, kk, 0, b4a, nu, nv);  // step n: the new row p - 4 ...
+		stages(A, p, kk, std::integral_constant<int, (FED < 8 ? FED : 8)>{}, 0, b4a, nu, nv);  // step n: the new row p - 4 ...
 #endif
 #if !defined(CRD_PROBE_HALFMATH) && !defined(CRD_PROBE_NOMATH)
 		B.u0[S0] = nu;                            // ... is the second pipeline's newest row (same slot: rows shifted by 4)
 		B.v0[S0] = nv;
 		B.bq[S0] = b4a;
-		stages(B, p - kApron, kk, 4, b4b, nu, nv);  // step n + 1: the new row p - 8
+		stages(B, p - kApron, kk, std::integral_constant<int, (FED < 8 ? 0 : FED - 8)>{}, 4, b4b, nu, nv);  // step n + 1: the new row p - 8
 #endif
 #ifndef CRD_PROBE_NOSTORE
 		if (m >= 4 * kApron && lane_stores) {  // rows j0 .. j1 - 1 exactly
@@ -731,13 +746,21 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		}
 	};
 	int m = 0;
+	for_sequence(  // the pipeline fills (a chunk has at least one row: sixteen iterations and more)
+	    [&](auto i) {
+		    constexpr int I = decltype(i)::value;
+		    iteration(I, std::integral_constant<int, I % M>{}, i);
+		    if constexpr (I % M == M - 1) next_trip();
+	    },
+	    std::make_integer_sequence<int, 4 * kApron>{});
+	m = 4 * kApron;
 	for (; m + M - 1 < niter; m += M) {
-		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k); }, std::make_integer_sequence<int, M>{});
+		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::integral_constant<int, 4 * kApron>{}); }, std::make_integer_sequence<int, M>{});
 		next_trip();
 	}
 	for_sequence(
 	    [&](auto k) {
-		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k);
+		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::integral_constant<int, 4 * kApron>{});
 	    },
 	    std::make_integer_sequence<int, M - 1>{});
 	// the fills still in flight write LDS: they must have landed before the wavefront ends and its LDS goes to the next workgroup
@@ -1145,7 +1168,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	// repeating it is harmless: every candidate writes the same values), then reused for every launch of similar height.
 	FusedPlan *plan = c.plan;
 	const bool plannable = plan && rows2 == 0 && (long)rows * d.nx >= (1L << 20) && !tuning::enabled();  // (under CRD_TUNING the knobs decide)
-	if (plannable && !plan->tuned && plan->autotune) {
+	if (plannable && !plan->tuned && plan->autotune && !c.geometry) {
 		hipEvent_t e0 = nullptr, e1 = nullptr;
 		// (nothing else may run on the device while candidates are timed: a halo exchange still in flight on the second stream
 		// made a ring context pick a different -- worse -- plan than a plain slab of the same shape)
@@ -1280,6 +1303,29 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const bool pinned = plan && plan->tuned && plan->pinned && !tuning::enabled();
 	const bool use_plan = (plannable && plan->tuned && 10L * rows >= 9L * plan->rows && 10L * rows <= 11L * plan->rows) || (pinned && rows2 == 0);
 	configure(use_plan ? plan->one_round : 0, use_plan ? plan->remap : 0, (plan && plan->tuned) ? plan->cols : cols_default, (use_plan || pinned) ? plan->nt : 0, c.steps);
+	if (c.geometry) {
+		FusedGeometry &g = *c.geometry;
+		const int apron = steps * (c.embed ? kApron + 1 : kApron);
+		g.real_bytes = (int)sizeof(Real);
+		g.model = MODEL;
+		g.absorb = steps == 2 ? 0 : (absorb1 ? 1 : 0);  // (two steps with absorbing rows on: the bulk goes out as the select-free kernel)
+		g.embed = c.embed;
+		g.cols = cols;
+		g.nt = nt ? 1 : 0;
+		g.steps = steps;
+		g.strips = a.nstrips;
+		g.chunk_rows = a.chunk;
+		g.chunks = a.nchunks;
+		g.blocks = a.nblocks;
+		g.waves_per_block = sw;
+		g.fill_iterations = 2 * apron;
+		g.iterations_per_trip = c.embed ? CRD_EMBED_SLOTS : 4;
+		g.lanes = kLanes;
+		g.lanes_valid = (cols * kLanes - 2 * apron) / cols;
+		g.mapping = a.remap;
+		g.wave_iterations = (long)a.nstrips * ((long)(rows + rows2) + (long)a.nchunks * 2 * apron);
+		return hipSuccess;
+	}
 	return fire();
 }
 

@@ -73,6 +73,20 @@ struct FusedPlan {
 	float ms_default = 0.f, ms_best = 0.f;  // measured launch times of the plain plan and of the chosen one
 };
 
+// What a launch_fused_step call WOULD launch (filled instead of launching when FusedCall::geometry is set): the instantiation and how
+// the rows are cut.  With the kernel table of the build (step_kernel_stats) it prices a launch's vector issue without a profiler.
+struct FusedGeometry {
+	int real_bytes, model, absorb, embed, cols, nt, steps;  // template arguments of the kernel
+	int strips, chunk_rows, chunks, blocks, waves_per_block, fill_iterations, iterations_per_trip, lanes, lanes_valid, mapping;
+	long wave_iterations;  // pipeline iterations of all wavefronts of the launch: strips x (rows + chunks x fill)
+};
+// One step kernel of this build as the assembler printed it (crd_kernel_table.cpp, generated at build time by tools/kernel_regs.py):
+// registers, occupancy, and the static instruction mix of one trip of the steady-state loop.
+struct KernelStats {
+	int real_bytes, model, absorb, embed, cols, nt, steps, vgprs, sgprs, lds_bytes, scratch_bytes, wavefronts_per_simd, loop_valu, loop_salu, loop_vmem, loop_lds, loop_total;
+};
+const KernelStats *step_kernel_stats(int real_bytes, int model, int absorb, int embed, int cols, int nt, int steps);  // nullptr: the build has no table
+
 struct FusedCall {
 	double dt;
 	int absorb[5];  // four stages + the embedded pair's fifth (embed = 1: t + dt; embed = 2: t + 3/4 dt)
@@ -91,6 +105,7 @@ struct FusedCall {
 	// launch reading what the previous one wrote as real stepping does, instead of repeating y0 -> yout (whose input, never
 	// overwritten, stays in the 256 MB memory-side cache on slabs that fit: a one-GPU share of an 8-GPU run does).
 	Planes tune_scratch{nullptr, nullptr};
+	FusedGeometry *geometry = nullptr;  // set: nothing is launched or measured, *geometry says what the call would launch
 };
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s);

@@ -79,6 +79,7 @@ int staged_step_multi(crd_ctx *const *cs, int n, double t, double dt, bool timed
 			if (int rc = set_device(c)) return rc;
 			const StageCall call = make_stage_call(c, stage, t, dt);
 			const bool timed = timed_step && stage == 2 && !c->ev_k.empty();
+			if (timed) c->timed_steps = 1;
 			if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[0], c->compute));
 			HIP_TRY(c, launch_stage(c->p.precision, c->desc, call, 1, c->nyl - 1, c->compute));
 			if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
@@ -184,6 +185,7 @@ int fused_launch_multi(crd_ctx *const *cs, int n, double t, double dt, int src, 
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));
 				if (timed) HIP_TRY(c, hipEventRecord(c->ev_k[1], c->compute));
 				if (timed) c->timed_rows = c->nyl + 2 * ext;  // what crd_dominant_kernel_rows reports for this launch
+				if (timed) c->timed_steps = nsub;
 				continue;
 			}
 			// First launch after an exchange.  Output rows [H, nyl - H) read owned rows only, so they are launched straight behind
@@ -337,21 +339,24 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		for (int64_t s = 0; s < nsteps;) {
 			const double t = t0 + (double)s * dt;
 			hipEvent_t *kb = nullptr, *ke = nullptr;
-			// every fourth step at most: an event pair around EVERY launch of a short run would sit inside the region being timed
+			// The plan may say "two steps per launch" (measured, or pinned): pairs while two steps are left, a single-step launch
+			// for an odd last one (pair_is_exact: see there).
+			const bool pairing = stepper == CRD_STEPPER_FUSED && c->plan.tuned && c->plan.steps == 2 && fused_two_steps_supported(c->desc);
+			int rc, took = (pairing && s + 2 <= nsteps && pair_is_exact(c, t0, s, dt)) ? 2 : 1;
+			// every fourth step at most: an event pair around EVERY launch of a short run would sit inside the region being timed.  Only
+			// launches of the plan's own kind are timed (a pairing plan's odd last step, or a pair stepped singly, goes out as a one-step
+			// launch: another kernel, which must not enter the average; runs too short to hold a pair time what there is).
 			const int64_t want = std::min<int64_t>(kMaxTimedLaunches, std::max<int64_t>(1, nsteps / 4));
-			if (timed_launches && timed < want && (s * want / std::max<int64_t>(nsteps, 1)) >= timed && ((s % 4) >= 1 || nsteps < 4)) {
+			const int kind = (pairing && nsteps >= 2) ? 2 : 1;
+			if (timed_launches && timed < want && took == kind && (s * want / std::max<int64_t>(nsteps, 1)) >= timed && ((s % 4) >= 1 || nsteps < 4)) {
 				kb = &c->ev_k[(size_t)(2 * timed)];
 				ke = &c->ev_k[(size_t)(2 * timed + 1)];
 				timed++;
+				c->timed_steps = took;
 			}
-			int rc, took = 1;
 			if (stepper == CRD_STEPPER_STAGED) {
 				rc = staged_step_self(c, t, dt, kb, ke);
 			} else {
-				// The plan may say "two steps per launch" (measured, or pinned): pairs while two steps are left, a single-step launch
-				// for an odd last one (pair_is_exact: see there).
-				const bool pair = c->plan.tuned && c->plan.steps == 2 && s + 2 <= nsteps && fused_two_steps_supported(c->desc);
-				took = (pair && pair_is_exact(c, t0, s, dt)) ? 2 : 1;
 				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
 				rc = fused_step_self(c, t, dt, cur, dst, kb, ke, took);
 				cur = dst;
@@ -495,7 +500,7 @@ int crd_step_rk4(crd_ctx *c, double t0, double dt, int64_t nsteps)
 // a thread needs a good part of that to issue one GPU's work).  The threads run the same step loop on their own contexts and meet
 // at the group's rendezvous around every halo exchange.  crd_group_set_threads(ctxs, n, k) forces k threads (also on one device:
 // how the tests exercise the rendezvous on a one-GPU box), k = 1 the single-thread path.
-int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps)
+static int group_step(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps, bool timed)
 {
 	if (int rc = check_group(ctxs, n)) return rc;
 	if (n > 1)
@@ -515,14 +520,15 @@ int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_
 	const int nthreads = (int)first.size();
 	decide_cycle_start(ctxs, n);
 	TraceRange range("crd_group_step_rk4");
-	if (nthreads <= 1 || nsteps <= 0) return run_steps(ctxs, n, t0, dt, nsteps, nullptr);
+	std::vector<int> timed_of((size_t)nthreads, 0);
+	if (nthreads <= 1 || nsteps <= 0) return run_steps(ctxs, n, t0, dt, nsteps, timed ? &timed_of[0] : nullptr);
 	first.push_back(n);
 	GroupBarrier bar;
 	bar.members = nthreads;
 	for (int k = 0; k < n; k++) ctxs[k]->bar = &bar;
 	std::vector<int> rcs((size_t)nthreads, CRD_OK);
 	auto work = [&](int q) {
-		rcs[(size_t)q] = run_steps(ctxs + first[(size_t)q], first[(size_t)q + 1] - first[(size_t)q], t0, dt, nsteps, nullptr);
+		rcs[(size_t)q] = run_steps(ctxs + first[(size_t)q], first[(size_t)q + 1] - first[(size_t)q], t0, dt, nsteps, timed ? &timed_of[(size_t)q] : nullptr);
 		if (rcs[(size_t)q] != CRD_OK) bar.leave_failed();
 	};
 	std::vector<std::thread> pool;
@@ -823,6 +829,10 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 	// One attempt of size hh at time tt from plane `src` into plane `dst`, enqueued only: the kernel, the fixed-order sum of its
 	// partials, and -- on the second stream, behind an event -- the reduction over the ranks and the copy of the scalar to
 	// page-locked memory.  `slot` (0 / 1) names the buffers; finish_attempt(slot) waits for the scalar.
+	// The two attempt slots (an attempt and the one launched ahead of its verdict) have scalars of their own -- elements 2 and 3; 0 is
+	// collect_scalar's / crd_state_max_abs's, which run on the compute stream with no ordering against a slot's second-stream work.
+	constexpr int kAttemptScalar = 2;
+	bool in_flight[2] = {false, false};  // launched and not yet waited for
 	auto launch_attempt = [&](double tt, double hh, int src, int dst, int slot) -> int {
 		if (ext_of[src] < kEmbedHalo) {
 			if (int rc = prime_halo(cs, n, src, kAdaptGhost, true)) return rc;
@@ -848,19 +858,20 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			// (the slot's previous user may have been launched ahead and never waited for: its reduction on the second stream must be
 			// through with the slot's device scalar before this attempt's sum lands there)
 			if (reduce_on_device) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_norm[slot], 0));
-			call.err_sum = reduce_on_device ? c->scalar_dev + slot : c->scalar_host + slot;  // (the sum kernel writes page-locked memory directly unless ranks still have to be added)
+			call.err_sum = reduce_on_device ? c->scalar_dev + kAttemptScalar + slot : c->scalar_host + kAttemptScalar + slot;  // (the sum kernel writes page-locked memory directly unless ranks still have to be added)
 			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -e, c->nyl + e, 0, 0, c->compute));
 			if (reduce_on_device) {
 				HIP_TRY(c, hipEventRecord(c->ev_attempt[slot], c->compute));
 				HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_attempt[slot], 0));
-				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev + slot, c->scalar_dev + slot, 1, ncclDouble, ncclSum, c->nccl, c->comm));  // (every rank gets the same bits, hence takes the same decision)
-				HIP_TRY(c, hipMemcpyAsync(c->scalar_host + slot, c->scalar_dev + slot, sizeof(double), hipMemcpyDeviceToHost, c->comm));
+				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev + kAttemptScalar + slot, c->scalar_dev + kAttemptScalar + slot, 1, ncclDouble, ncclSum, c->nccl, c->comm));  // (every rank gets the same bits, hence takes the same decision)
+				HIP_TRY(c, hipMemcpyAsync(c->scalar_host + kAttemptScalar + slot, c->scalar_dev + kAttemptScalar + slot, sizeof(double), hipMemcpyDeviceToHost, c->comm));
 				HIP_TRY(c, hipEventRecord(c->ev_norm[slot], c->comm));
 			} else {
 				HIP_TRY(c, hipEventRecord(c->ev_norm[slot], c->compute));
 			}
 		}
 		ext_of[dst] = multi ? e : (1 << 20);
+		in_flight[slot] = true;
 		return CRD_OK;
 	};
 	auto finish_attempt = [&](int slot, double *sum) -> int {
@@ -869,8 +880,9 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			crd_ctx *c = cs[k];
 			if (int rc = set_device(c)) return rc;
 			HIP_TRY(c, hipEventSynchronize(c->ev_norm[slot]));
-			acc += c->scalar_host[slot];
+			acc += c->scalar_host[kAttemptScalar + slot];
 		}
+		in_flight[slot] = false;
 		*sum = acc;
 		return CRD_OK;
 	};
@@ -1026,10 +1038,13 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			h = hh * std::fmin(eta, 0.9);
 		}
 	}
-	if (ahead.live) {  // (cannot happen -- nothing is launched ahead of the last step -- but a void launch must never outlive the call)
-		double ignored;
-		(void)finish_attempt(ahead.slot, &ignored);
-	}
+	// No launch outlives the call -- neither a void one (issued ahead of a verdict that then went the other way) nor, on an error exit,
+	// the attempt that was being waited for: their reductions and copies on the second stream still write the slots' scalars.
+	for (int slot = 0; slot < 2; slot++)
+		if (in_flight[slot]) {
+			double ignored;
+			(void)finish_attempt(slot, &ignored);
+		}
 	st.t_internal = t;
 	if (rc == CRD_OK && dense && prev >= 0 && t >= tout) {
 		// ARK_NORMAL: the step t_prev -> t has reached or passed tout.  f at both ends, then the cubic Hermite interpolant at tout.
@@ -1143,6 +1158,45 @@ int crd_get_step_timing(const crd_ctx *c, crd_step_timing *out)
 	return CRD_OK;
 }
 
+int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps) { return group_step(ctxs, n, t0, dt, nsteps, false); }
+
+// The group call with the clocks of crd_step_rk4_timed on every slab: an event pair around the batch on each context's compute stream
+// and one around ONE full-height launch of the dominant kernel per context, mid-run (a launch of the exchange cycle that is neither
+// its split first nor its split last).  Returns when every slab's last step is done; crd_get_step_timing(ctxs[k]) has slab k's figures.
+int crd_group_step_rk4_timed(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps)
+{
+	if (int rc = check_group(ctxs, n)) return rc;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = ctxs[k];
+		if (int rc = set_device(c)) return rc;
+		if (int rc = ensure_timing_events(c)) return rc;
+		c->timed_rows = c->timed_steps = 0;
+		c->timing = crd_step_timing{};
+		HIP_TRY(c, hipEventRecord(c->ev_t0, c->compute));
+	}
+	if (int rc = group_step(ctxs, n, t0, dt, nsteps, true)) return rc;
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = ctxs[k];
+		if (int rc = set_device(c)) return rc;
+		HIP_TRY(c, hipEventRecord(c->ev_t1, c->compute));
+	}
+	for (int k = 0; k < n; k++) {
+		crd_ctx *c = ctxs[k];
+		if (int rc = set_device(c)) return rc;
+		HIP_TRY(c, hipEventSynchronize(c->ev_t1));
+		HIP_TRY(c, hipStreamSynchronize(c->comm));
+		float ms = 0.f, km = 0.f;
+		HIP_TRY(c, hipEventElapsedTime(&ms, c->ev_t0, c->ev_t1));
+		if (c->timed_steps > 0) HIP_TRY(c, hipEventElapsedTime(&km, c->ev_k[0], c->ev_k[1]));  // (set where a launch of this context was timed)
+		c->timing.ms_total = ms;
+		c->timing.kernel_ms = km;
+		c->timing.steps = nsteps;
+		c->timing.halo_slack = c->halo_slack;
+		c->timing.timed_steps_per_launch = c->timed_steps;
+	}
+	return CRD_OK;
+}
+
 int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double *ms_total, double *kernel_ms, int *launches_per_step)
 {
 	if (!c) return CRD_EINVAL;
@@ -1159,7 +1213,7 @@ int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double 
 	crd_ctx *one[1] = {c};
 	decide_cycle_start(one, 1);
 	int timed = 0;
-	c->timed_rows = 0;
+	c->timed_rows = c->timed_steps = 0;
 	c->diag_waits = c->diag_exchanges = 0;
 	c->diag_active = c->diagnostics && c->halo == CRD_HALO_RCCL;
 	c->timing = crd_step_timing{};
@@ -1188,6 +1242,7 @@ int crd_step_rk4_timed(crd_ctx *c, double t0, double dt, int64_t nsteps, double 
 	tm.kernel_ms = timed ? sum / timed : 0.0;
 	tm.steps = nsteps;
 	tm.halo_slack = c->halo_slack;
+	tm.timed_steps_per_launch = timed ? c->timed_steps : 0;
 	tm.halo_waits = c->diag_waits;
 	tm.exchanges = c->diag_exchanges;
 	for (int k = 0; k < c->diag_waits; k++) {

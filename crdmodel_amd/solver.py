@@ -332,6 +332,12 @@ class Slab:
         self._check(lib().crd_get_launch_plan(self._h, C.byref(lp)), "crd_get_launch_plan")
         return {f: getattr(lp, f) for f, _ in lp._fields_ if f != "reserved"}
 
+    def launch_geometry(self):
+        """The full-height launch under the current plan + what the build's kernel table says about its kernel (crd_launch_geometry)."""
+        g = capi.LaunchGeometry()
+        self._check(lib().crd_get_launch_geometry(self._h, C.byref(g)), "crd_get_launch_geometry")
+        return {f: getattr(g, f) for f, _ in g._fields_ if f != "reserved"}
+
     def max_abs(self):
         v = C.c_double()
         self._check(lib().crd_state_max_abs(self._h, C.byref(v)), "crd_state_max_abs")
@@ -446,6 +452,11 @@ class LocalGroup:
         check(lib().crd_group_step_rk4(self._arr, len(self.slabs), t0, dt, nsteps), "crd_group_step_rk4", self.slabs[0].handle)
         for s in self.slabs:
             s.synchronize()
+
+    def step_rk4_timed(self, t0, dt, nsteps):
+        """crd_group_step_rk4_timed: the group call with event pairs on every slab; returns each slab's step_timing()."""
+        check(lib().crd_group_step_rk4_timed(self._arr, len(self.slabs), t0, dt, nsteps), "crd_group_step_rk4_timed", self.slabs[0].handle)
+        return [s.step_timing() for s in self.slabs]
 
     def set_stepper(self, stepper):
         for s in self.slabs:

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CRD_ABI_VERSION 4
+#define CRD_ABI_VERSION 5
 
 typedef enum crd_status {
 	CRD_OK = 0,
@@ -374,6 +374,10 @@ int crd_group_integrate_adaptive(crd_ctx *const *ctxs, int n, double t0, double 
 /* LOCAL groups (several slabs driven by one host thread): the same two operations on every slab of the run in
  * lockstep; ctxs[k] must be slab k of n.  y[k] / ydot[k] are device pointers on ctxs[k]'s device. */
 int crd_group_step_rk4(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps);
+/* ... with the clocks of crd_step_rk4_timed (below) on every slab: device time of the batch and the duration of one full-height
+ * launch of the dominant kernel per context; crd_get_step_timing(ctxs[k]) returns slab k's figures.  Returns when every slab's last
+ * step is done. */
+int crd_group_step_rk4_timed(crd_ctx *const *ctxs, int n, double t0, double dt, int64_t nsteps);
 /* Host threads that issue a group's work in crd_group_step_rk4: 0 (default) = one per device the group is spread over, k >= 1 =
  * exactly k (contiguous runs of slabs per thread; k = 1: the calling thread alone).  The threads meet at a host rendezvous around
  * every halo exchange; results do not depend on k. */
@@ -402,7 +406,7 @@ typedef struct crd_step_timing {
 	double exchange_ms;         /* sum over exchanges */
 	int64_t steps;
 	int32_t halo_slack;         /* crd_set_halo_slack at the time of the call */
-	int32_t reserved;
+	int32_t timed_steps_per_launch; /* RK4 steps one of the timed launches advanced: 1, or 2 (a two-steps-per-launch plan); 0: none timed */
 	int32_t halo_waits;         /* waits measured (at most 64 per call) */
 	int32_t exchanges;          /* exchanges measured */
 	int64_t agreement_restarts; /* stepping calls of this context that started afresh with an exchange because the ring's ranks stood
@@ -447,6 +451,24 @@ typedef struct crd_launch_plan {
 } crd_launch_plan;
 int crd_set_autotune(crd_ctx *ctx, int on);
 int crd_get_launch_plan(const crd_ctx *ctx, crd_launch_plan *out);
+/* What the context's full-height launch of the step kernel looks like under its current plan, and what the assembler printed about
+ * the instantiation it runs (read off the device assembly when the library was built: tools/kernel_regs.py) -- enough to price the
+ * launch's vector issue without a profiler: loop_valu x (wavefront_iterations / iterations_per_trip) x 4 cycles per wavefront
+ * instruction over simds x clock (bench.py: roofline.issue_frac).  No reference counterpart. */
+typedef struct crd_launch_geometry {
+	int32_t rows;                      /* rows the launch produces (a multi-slab context: the launch the timed calls time) */
+	int32_t strips, chunk_rows, chunks; /* work items: strips of columns (one per wavefront) x chunks of rows */
+	int32_t workgroups, wavefronts_per_workgroup;
+	int32_t fill_iterations;           /* pipeline iterations an item runs beyond its rows (the aprons in phi) */
+	int32_t iterations_per_trip;       /* pipeline iterations one trip of the steady-state loop holds (its unroll factor) */
+	int32_t lanes, lanes_valid;        /* lanes of a wavefront / lanes whose column is an output */
+	int32_t vgprs, sgprs, lds_bytes, scratch_bytes, wavefronts_per_simd; /* of the instantiation; 0: the build carries no kernel table */
+	int32_t loop_valu, loop_salu, loop_vmem, loop_lds, loop_instructions; /* static instruction mix of one trip of that loop */
+	int32_t simds, clock_khz;          /* of the device: 4 x compute units, hipDeviceProp_t::clockRate */
+	int32_t reserved;
+	int64_t wavefront_iterations;      /* pipeline iterations all wavefronts of the launch run: strips x (rows + chunks x fill_iterations) */
+} crd_launch_geometry;
+int crd_get_launch_geometry(crd_ctx *ctx, crd_launch_geometry *out);
 /* The plans the measurement chooses among, index 0 .. (first index that returns CRD_EINVAL) - 1: one_round, xcd_mapping,
  * columns_per_lane, nontemporal_stores and steps_per_launch of *out are set, the rest zero.  (tools/plan_sweep.py profiles every one of them;
  * tests/test_profiles.py checks that profiles/pmc_traffic.json has an entry for each.) */

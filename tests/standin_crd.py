@@ -161,6 +161,13 @@ class LocalGroup:
     def step_rk4(self, t0, dt, nsteps):
         self.steps += nsteps
 
+    def step_rk4_timed(self, t0, dt, nsteps):
+        """One crd_step_timing-like dict per slab; STANDIN_NO_TIMED_LAUNCH: a run too short for any launch to be event-timed."""
+        self.steps += nsteps
+        spl = self.slabs[0].launch_plan()["steps_per_launch"]
+        timed = not os.environ.get("STANDIN_NO_TIMED_LAUNCH")
+        return [{"ms_total": 0.06 * nsteps, "kernel_ms": 0.055 if timed else 0.0, "steps": nsteps, "timed_steps_per_launch": spl if timed else 0} for _ in self.slabs]
+
     def close(self):
         for s in self.slabs:
             s.close()

@@ -249,6 +249,9 @@ def test_bench_multi_rank_control_flow(tmp_path, world, exposed_rank):
     else:
         assert halo["slack"]["sweeps"] == 1 and halo["slack"]["rehearsal_exposed_halo_ms_max_over_ranks"] == pytest.approx([0.011])
     assert [r["rank"] for r in d["per_rank"]] == list(range(world))
+    # "did RCCL see N ranks, did the exchange hide" at a glance: communicator size, self-check, period, slack and every rank's exposed wait
+    assert halo["exchange_period"]["steps"] == 8 and len(halo["exposed_halo_ms_per_rank"]) == world == len(halo["exchange_ms_per_rank"])
+    assert halo["exposed_halo_ms_per_rank"] == [r["exposed_halo_ms"] for r in d["per_rank"]]
     assert all(r["halo_slack"] == halo["slack"]["sweeps"] and r["exchanges"] == 3 and r["kernel_ms"] == 0.055 for r in d["per_rank"])
     assert d["roofline"]["kernel"] == "crd_rk4_fused_step_kernel" and d["roofline"]["bound"] == "hbm" and d["config"]["decomposition"] == "phi-slabs x%d" % world
 
@@ -299,6 +302,15 @@ def test_bench_falls_back_to_the_local_transport_and_runs_it_on_request():
     rf = d["roofline"]
     assert rf["plan_key"].endswith("/steps2") and rf["steps_per_launch"] == 2 and rf["one_step_per_launch_equivalent"]["frac"] == pytest.approx(2 * rf["frac"])
     assert rf["frac_wall"] == pytest.approx(4 * 8 * 64 * 64 / 2 / (d["ms_per_step"] * 1e-3) / 1e9 / 2 / 8000.0, rel=1e-9)
+    # the kernel time is slab 0's event-timed launch (crd_group_step_rk4_timed), priced with that launch's own rows and steps
+    assert rf["kernel_ms"] == 0.055 and "crd_group_step_rk4_timed" in rf["kernel_ms_source"] and [q["kernel_ms"] for q in d["per_rank"]] == [0.055, 0.055]
+    assert rf["frac"] == pytest.approx(4 * 8 * 64 * (32 + 48) / 0.055e-3 / 1e9 / 8000.0, rel=1e-9)
+    # ... and where no launch was event-timed the wall time per LAUNCH stands in (round-4 advice: per step it read twice the fraction): two
+    # equal slabs, so the launch-time fraction and the wall-time fraction are the same number
+    r = _run_bench(["--gpus", "2", "--size", "64", "--transport", "local"] + common, extra_env={"STANDIN_STEPS_PER_LAUNCH": "2", "STANDIN_NO_TIMED_LAUNCH": "1"})
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    rf = json.loads(r.stdout.strip().splitlines()[-1])["roofline"]
+    assert rf["steps_per_launch"] == 2 and rf["frac"] == pytest.approx(rf["frac_wall"], rel=1e-9) and "wall clock per launch" in rf["kernel_ms_source"]
     # the ring's leg fails on every rank (exchange period out of range -> the stand-in's assertion), auto falls back
     r = _run_bench(["--gpus", "2", "--size", "64", "--exchange-period", "2"] + common)
     assert r.returncode != 0  # ... unless the local leg fails for the same reason: it does (same bad period), and the status says so

@@ -1,31 +1,139 @@
 #!/usr/bin/env python3
-"""Register / scratch / occupancy table of every kernel in a .hip file (hipcc -Rpass-analysis=kernel-resource-usage).
-    tools/kernel_regs.py crdmodel_amd/csrc/crd_fused.hip [extra hipcc flags]"""
+"""Registers, occupancy and the instruction mix of the steady-state loop of every kernel in a .hip file or in device assembly.
+
+    tools/kernel_regs.py crdmodel_amd/csrc/crd_fused.hip [extra hipcc flags]      # compiles (hipcc -S, device only), prints the table
+    tools/kernel_regs.py --asm build/x-hip-amdgcn-amd-amdhsa-gfx950.s ...         # reads assembly the build kept (-save-temps=obj)
+        [--table build/crd_kernel_table.inc]   the step kernels' rows as C initialisers (compiled into libcrd: crd_get_launch_geometry)
+        [--json profiles/r05/kernel_table.json]
+
+The loop is the kernel's largest loop by vector instructions (the pipeline's steady state: the unrolled iterations of one trip);
+counts are static -- instructions in the loop body between its header label and its back edge, whatever branches inside it skip.
+VALU = every v_* instruction (DPP moves included); what issue costs a launch is VALU x trips x 4 cycles per wavefront (bench.py:
+roofline.issue_frac)."""
+import argparse
+import json
 import os
 import re
 import subprocess
 import sys
 
-root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = sys.argv[1]
-cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(root, "include"), "-I/opt/rocm/include",
-       "-I" + os.path.join(root, "crdmodel_amd", "csrc"), "-c", src, "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage"] + sys.argv[2:]
-out = subprocess.run(cmd, capture_output=True, text=True).stderr
-cur = None
-rows = {}
-for line in out.splitlines():
-    m = re.search(r"remark: \s*(Function Name|VGPRs|TotalSGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|LDS Size \[bytes/block\]): (.*?) \[-Rpass", line)
-    if not m:
-        if "error" in line:
-            print(line)
-        continue
-    k, v = m.group(1), m.group(2)
-    if k == "Function Name":
-        cur = subprocess.run(["c++filt", v], capture_output=True, text=True).stdout.strip()
-        cur = re.sub(r"\(anonymous namespace\)::|crd::|void ", "", cur).split("(")[0]
-        rows[cur] = {}
-    elif cur:
-        rows[cur][k.split(" ")[0]] = v
-print("%-64s %6s %6s %8s %5s %6s" % ("kernel", "VGPR", "SGPR", "scratch", "occ", "LDS"))
-for k, r in rows.items():
-    print("%-64s %6s %6s %8s %5s %6s" % (k[:64], r.get("VGPRs"), r.get("TotalSGPRs"), r.get("ScratchSize"), r.get("Occupancy"), r.get("LDS")))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def compile_to_asm(src, flags):
+    out = "/tmp/kernel_regs_%d.s" % os.getpid()
+    cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I/opt/rocm/include",
+           "-I" + os.path.join(ROOT, "crdmodel_amd", "csrc"), "--offload-device-only", "-S", src, "-o", out] + flags
+    res = subprocess.run(cmd, capture_output=True, text=True)
+    if res.returncode != 0:
+        sys.exit(res.stderr[-3000:])
+    text = open(out).read()
+    os.unlink(out)
+    return text
+
+
+def demangle(names):
+    res = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True).stdout.splitlines()
+    return [re.sub(r"\(anonymous namespace\)::|crd::|^void ", "", r).split("(")[0] for r in res]
+
+
+def classify(op):
+    if op.startswith("v_"):
+        return "valu"
+    if op.startswith(("buffer_", "global_", "scratch_", "flat_")):
+        return "vmem"
+    if op.startswith("ds_"):
+        return "lds"
+    if op.startswith("s_") and not op.startswith(("s_waitcnt", "s_nop", "s_barrier", "s_cbranch", "s_branch", "s_endpgm", "s_sleep")):
+        return "salu"
+    return "other"
+
+
+def parse(text):
+    """[{name (mangled), vgprs, sgprs, scratch, occupancy, lds, loop: {valu, salu, vmem, lds, other, total}}] for every kernel."""
+    kernels = []
+    lines = text.splitlines()
+    starts = [i for i, ln in enumerate(lines) if re.match(r"^(_Z\w+|\w+):\s*(;.*)?$", ln) and not ln.startswith(".")]
+    for n, i in enumerate(starts):
+        name = lines[i].split(":")[0]
+        end = starts[n + 1] if n + 1 < len(starts) else len(lines)
+        body = lines[i:end]
+        meta = {}
+        for ln in body:
+            m = re.match(r"\s*;\s*(NumVgprs|NumSgprs|TotalNumSgprs|ScratchSize|Occupancy|LDSByteSize):\s*(\d+)", ln)
+            if m:
+                meta[m.group(1)] = int(m.group(2))
+        if "NumVgprs" not in meta:
+            continue  # not a kernel (a label of some other kind)
+        # loops: header labels and the last branch back to each
+        label_at = {}
+        for k, ln in enumerate(body):
+            m = re.match(r"^(\.LBB\d+_\d+):", ln)
+            if m:
+                label_at[m.group(1)] = k
+        best = None
+        for label, k0 in label_at.items():
+            if "Loop Header" not in body[k0] and not (k0 + 1 < len(body) and body[k0 + 1].lstrip().startswith(";") and "Loop Header" in body[k0 + 1]):
+                continue
+            back = [k for k in range(k0, len(body)) if re.match(r"\s*s_c?branch\w*\s+" + re.escape(label) + r"\s*$", body[k])]
+            if not back:
+                continue
+            mix = {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0}
+            for ln in body[k0:back[-1] + 1]:
+                ln = ln.strip()
+                if not ln or ln.startswith((";", ".")) or ln.endswith(":"):
+                    continue
+                mix[classify(ln.split()[0])] += 1
+            mix["total"] = sum(mix.values())
+            if best is None or mix["valu"] > best["valu"]:
+                best = mix
+        kernels.append({"mangled": name, "vgprs": meta.get("NumVgprs", 0), "sgprs": meta.get("TotalNumSgprs", meta.get("NumSgprs", 0)), "scratch": meta.get("ScratchSize", 0),
+                        "occupancy": meta.get("Occupancy", 0), "lds": meta.get("LDSByteSize", 0), "loop": best or {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0, "total": 0}})
+    for k, nm in zip(kernels, demangle([k["mangled"] for k in kernels])):
+        k["name"] = nm
+    return kernels
+
+
+STEP_KERNEL = re.compile(r"crd_rk4_fused_step_kernel<(double|float), (\d+), (true|false), (\d+), (\d+), (true|false), (\d+)>")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("source", nargs="?")
+    ap.add_argument("--asm", nargs="*", default=[])
+    ap.add_argument("--table", default="")
+    ap.add_argument("--json", default="")
+    a, extra = ap.parse_known_args()
+    kernels = []
+    if a.source:
+        kernels += parse(compile_to_asm(a.source, extra))
+    for path in a.asm:
+        kernels += parse(open(path).read())
+    print("%-64s %5s %5s %7s %4s %6s | loop: %5s %5s %5s %4s %6s" % ("kernel", "VGPR", "SGPR", "scratch", "occ", "LDS", "VALU", "SALU", "VMEM", "LDS", "total"))
+    for k in kernels:
+        lp = k["loop"]
+        print("%-64s %5d %5d %7d %4d %6d | %11d %5d %5d %4d %6d" % (k["name"][:64], k["vgprs"], k["sgprs"], k["scratch"], k["occupancy"], k["lds"], lp["valu"], lp["salu"],
+                                                                     lp["vmem"], lp["lds"], lp["total"]))
+    rows = []
+    for k in kernels:
+        m = STEP_KERNEL.search(k["name"])
+        if m:
+            real, model, absorb, embed, cols, nt, steps = m.groups()
+            rows.append({"precision": "f64" if real == "double" else "f32", "model": int(model), "absorb": int(absorb == "true"), "embed": int(embed), "cols": int(cols),
+                         "nt": int(nt == "true"), "steps": int(steps), "vgprs": k["vgprs"], "sgprs": k["sgprs"], "lds_bytes": k["lds"], "scratch_bytes": k["scratch"],
+                         "wavefronts_per_simd": k["occupancy"], "loop": k["loop"]})
+    if a.table:
+        with open(a.table, "w") as f:
+            f.write("// generated by tools/kernel_regs.py from the assembly of this build's step kernels -- do not edit\n")
+            for r in rows:
+                lp = r["loop"]
+                f.write("{%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},\n" % (
+                    8 if r["precision"] == "f64" else 4, r["model"], r["absorb"], r["embed"], r["cols"], r["nt"], r["steps"], r["vgprs"], r["sgprs"], r["lds_bytes"],
+                    r["scratch_bytes"], r["wavefronts_per_simd"], lp["valu"], lp["salu"], lp["vmem"], lp["lds"], lp["total"]))
+    if a.json:
+        json.dump({"_comment": "step kernels of this build: registers, occupancy and the static instruction mix of the steady-state loop (one trip = the unrolled "
+                               "pipeline iterations), from the code object's assembly (tools/kernel_regs.py)", "kernels": rows}, open(a.json, "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
