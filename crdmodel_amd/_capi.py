@@ -101,7 +101,7 @@ class LaunchGeometry(C.Structure):
 
     _fields_ = [(f, C.c_int32) for f in ("rows", "strips", "chunk_rows", "chunks", "workgroups", "wavefronts_per_workgroup", "fill_iterations", "iterations_per_trip",
                                          "lanes", "lanes_valid", "vgprs", "sgprs", "lds_bytes", "scratch_bytes", "wavefronts_per_simd", "loop_valu", "loop_salu",
-                                         "loop_vmem", "loop_lds", "loop_instructions", "simds", "clock_khz", "reserved")] + [("wavefront_iterations", C.c_int64)]
+                                         "loop_vmem", "loop_lds", "loop_instructions", "simds", "clock_khz", "reserved")] + [("wavefront_iterations", C.c_int64), ("wavefront_iterations_effective", C.c_int64)]
 
 
 class StepTiming(C.Structure):

@@ -756,6 +756,7 @@ int crd_get_launch_geometry(crd_ctx *c, crd_launch_geometry *out)
 	out->lanes_valid = g.lanes_valid;
 	out->rows = (int32_t)rows;
 	out->wavefront_iterations = g.wave_iterations;
+	out->wavefront_iterations_effective = g.wave_iterations - (int64_t)g.strips * g.chunks * (g.fill_iterations / 2 + 1);
 	if (const KernelStats *k = step_kernel_stats(g.real_bytes, g.model, g.absorb, g.embed, g.cols, g.nt, g.steps)) {
 		out->vgprs = k->vgprs;
 		out->sgprs = k->sgprs;

@@ -474,6 +474,25 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 	}
 }
 
+// y + h k of the stage updates as the three-address v_fma_f64, spelled out: left to itself the compiler forms a third of them as
+// v_mov_b64 + v_fmac_f64 (the addend is still needed, and its two-address form wants it in the destination) -- ten moves per iteration
+// of the two-step pipeline, 7 % of its vector instructions.  Same operation, same rounding.
+#ifndef CRD_NO_ASM_FMA
+__device__ __forceinline__ double stage_fma(double h, double k, double y)
+{
+	double d;
+	asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "s"(h), "v"(k), "v"(y));
+	return d;
+}
+#else
+__device__ __forceinline__ double stage_fma(double h, double k, double y) { return fmadd(h, k, y); }
+#endif
+template <typename V>
+__device__ __forceinline__ V stage_fma(V h, V k, V y)
+{
+	return fmadd(h, k, y);
+}
+
 // ---- the two-step pipeline's memory path (round 5) ----------------------------------------------------------------------------
 // Rows enter through LDS, fetched by LDS-DMA (buffer_load_dword ... lds) kRingRows iterations ahead of their use: the data of a
 // load in flight needs no vector register, so the depth of the prefetch is a matter of LDS (a wavefront's ring: kRingRows x
@@ -662,33 +681,33 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		if constexpr (live >= 2) {
 			rhs_lane<V, MODEL>(P.u0[S1], P.u0[S2], P.u0[S0], P.v0[S1], cE, cWn, cP, P.bq[S1], ka4,
 			                       ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), du, dv);
-			P.U1[S1] = fmadd(h2, du, P.u0[S1]);
-			P.V1[S1 & 1] = fmadd(h2, dv, P.v0[S1]);
-			P.aU[S1] = fmadd(h6, du, P.u0[S1]);
-			P.aV[S1] = fmadd(h6, dv, P.v0[S1]);
+			P.U1[S1] = stage_fma(h2, du, P.u0[S1]);
+			P.V1[S1 & 1] = stage_fma(h2, dv, P.v0[S1]);
+			P.aU[S1] = stage_fma(h6, du, P.u0[S1]);
+			P.aV[S1] = stage_fma(h6, dv, P.v0[S1]);
 		}
 		if constexpr (live >= 4) {
 			rhs_lane<V, MODEL>(P.U1[S2], P.U1[S3], P.U1[S1], P.V1[S2 & 1], cE, cWn, cP, P.bq[S2], ka4,
 			                       ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), du, dv);
-			P.U2[S2] = fmadd(h2, du, P.u0[S2]);
-			P.V2[S2 & 1] = fmadd(h2, dv, P.v0[S2]);
-			P.aU[S2] = fmadd(h3, du, P.aU[S2]);
-			P.aV[S2] = fmadd(h3, dv, P.aV[S2]);
+			P.U2[S2] = stage_fma(h2, du, P.u0[S2]);
+			P.V2[S2 & 1] = stage_fma(h2, dv, P.v0[S2]);
+			P.aU[S2] = stage_fma(h3, du, P.aU[S2]);
+			P.aV[S2] = stage_fma(h3, dv, P.aV[S2]);
 		}
 		if constexpr (live >= 6) {
 			rhs_lane<V, MODEL>(P.U2[S3], P.U2[S4], P.U2[S2], P.V2[S3 & 1], cE, cWn, cP, P.bq[S3], ka4,
 			                       ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), du, dv);
-			P.U3[S3] = fmadd(h1, du, P.u0[S3]);
-			P.V3[S3 & 1] = fmadd(h1, dv, P.v0[S3]);
-			P.aU[S3] = fmadd(h3, du, P.aU[S3]);
-			P.aV[S3] = fmadd(h3, dv, P.aV[S3]);
+			P.U3[S3] = stage_fma(h1, du, P.u0[S3]);
+			P.V3[S3 & 1] = stage_fma(h1, dv, P.v0[S3]);
+			P.aU[S3] = stage_fma(h3, du, P.aU[S3]);
+			P.aV[S3] = stage_fma(h3, dv, P.aV[S3]);
 		}
 		nu = nv = zero_v;
 		if constexpr (live >= 8) {
 			rhs_lane<V, MODEL>(P.U3[S4], P.U3[S5], P.U3[S3], P.V3[S4 & 1], cE, cWn, cP, b4, ka4,
 			                       ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), du, dv);
-			nu = fmadd(h6, du, P.aU[S4]);
-			nv = fmadd(h6, dv, P.aV[S4]);
+			nu = stage_fma(h6, du, P.aU[S4]);
+			nv = stage_fma(h6, dv, P.aV[S4]);
 		}
 	};
 	auto iteration = [&](int m, auto kk, auto fed_c) {

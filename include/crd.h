@@ -467,6 +467,8 @@ typedef struct crd_launch_geometry {
 	int32_t simds, clock_khz;          /* of the device: 4 x compute units, hipDeviceProp_t::clockRate */
 	int32_t reserved;
 	int64_t wavefront_iterations;      /* pipeline iterations all wavefronts of the launch run: strips x (rows + chunks x fill_iterations) */
+	int64_t wavefront_iterations_effective; /* ... with an item's filling iterations at what they cost: stage k of the pipeline starts at
+	                                    * iteration 2 k, so the fill runs fill_iterations / 2 - 1 iterations' worth of stages */
 } crd_launch_geometry;
 int crd_get_launch_geometry(crd_ctx *ctx, crd_launch_geometry *out);
 /* The plans the measurement chooses among, index 0 .. (first index that returns CRD_EINVAL) - 1: one_round, xcd_mapping,

@@ -384,7 +384,12 @@ def test_bench_line_end_to_end(gpu_device):
     assert (d["n_gpus"], d["steps"], d["warmup"], d["unit"], d["dtype"], d["higher_is_better"], d["vs_baseline"]) == (1, 8, 2, "grid-point-steps/s", "f64", True, None)
     assert d["value"] == pytest.approx(1024 * 1024 * 8 / (d["ms_per_step"] * 8e-3), rel=1e-9) and d["config"]["workload"].startswith("fhn_torus_1024x1024")
     r = d["roofline"]
-    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "crd_rk4_fused_step_kernel"
+    assert r["bound"] in ("hbm", "valu-issue") and r["unit"] == "GB/s" and r["peak"] == 8000.0 and r["kernel"] == "crd_rk4_fused_step_kernel"
+    # the same launch on the vector-issue roof, from the build's own kernel table and this run's launch geometry: a fraction of the SIMDs' time,
+    # and `bound` names the roof the launch sits closer to (a 1024^2 grid lives in the memory-side cache: issue)
+    iss = r["issue"]
+    assert 0.05 < r["issue_frac"] <= 1.1 and r["issue_frac"] == pytest.approx(iss["issue_floor_ms"] / r["kernel_ms"]) and iss["valu_instructions_per_trip"] > 100 and iss["simds"] == 1024
+    assert (r["bound"] == "valu-issue") == (r["issue_frac"] > 1.05 * r["frac_of_device_streaming"])
     assert r["frac"] == pytest.approx(r["achieved"] / r["peak"]) and 0.0 < r["frac"] <= 1.0 and 0.0 < r["kernel_ms"] <= 1.5 * d["ms_per_step"]
     assert r["algorithmic_bytes_per_launch"] == 32 * 1024 * 1024 and r["launches_per_step"] == 1
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["cores"] >= 1
