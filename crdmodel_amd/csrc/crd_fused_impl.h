@@ -19,6 +19,7 @@
 // invalidates one more apron column per side, hence 4 + 4 of 64; chunks start 4 rows early and end 4 rows late for the
 // same reason in phi (rows come from the slab's ghost rows, or wrap for a single slab).
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cstdint>
@@ -1104,12 +1105,16 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 			};
 			if (absorb1) with_nt(std::true_type{});
 			else with_nt(std::false_type{});
-			crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
+			if (c.done_event) hipExtLaunchKernelGGL(crd_sum_partials_kernel, dim3(1), dim3(256), 0, st, nullptr, c.done_event, 0, (const double *)c.err_partials, a.nitems, c.err_sum);
+			else crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
 		} else {
 			// plain step: absorbing rows x columns per lane x store hint x steps per launch, all compile-time
+			bool last_launch = true;  // (of this call: the one a done_event is bound to)
 			auto with = [&](auto absorb_c, auto cols_c, auto nt_c, auto steps_c) {
-				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value,
-				                          kCanTwoSteps ? decltype(steps_c)::value : 1><<<a.nblocks, block, 0, st>>>(s, a);
+				auto kernel = crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value,
+				                                        kCanTwoSteps ? decltype(steps_c)::value : 1>;
+				if (c.done_event && last_launch) hipExtLaunchKernelGGL(kernel, dim3(a.nblocks), block, 0, st, nullptr, c.done_event, 0, s, a);
+				else kernel<<<a.nblocks, block, 0, st>>>(s, a);
 			};
 			auto with_steps = [&](auto absorb_c, auto cols_c, auto nt_c) {
 				if (steps == 2) with(absorb_c, cols_c, nt_c, std::integral_constant<int, 2>{});
@@ -1159,8 +1164,9 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (!fits || n_with == 0) {
 					launch(true);
 				} else {
-					auto issue = [&](int (*piece)[2], int count, bool selects, int item_rows) {
+					auto issue = [&](int (*piece)[2], int count, bool selects, int item_rows, bool final_pieces) {
 						for (int q = 0; q < count; q += 2) {
+							last_launch = final_pieces && q + 2 >= count;
 							R[0] = piece[q][0];
 							R[1] = piece[q][1];
 							R[2] = q + 1 < count ? piece[q + 1][0] : 0;
@@ -1170,8 +1176,9 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 							launch(selects);
 						}
 					};
-					issue(with_sel, n_with, true, 3);
-					issue(without, n_without, false, 0);
+					issue(with_sel, n_with, true, 3, n_without == 0);
+					issue(without, n_without, false, 0, true);
+					last_launch = true;
 					for (int q = 0; q < 4; q++) R[q] = want[q];
 					chunk_override = 0;
 					layout();

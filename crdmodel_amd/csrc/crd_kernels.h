@@ -106,6 +106,10 @@ struct FusedCall {
 	// overwritten, stays in the 256 MB memory-side cache on slabs that fit: a one-GPU share of an 8-GPU run does).
 	Planes tune_scratch{nullptr, nullptr};
 	FusedGeometry *geometry = nullptr;  // set: nothing is launched or measured, *geometry says what the call would launch
+	// An event that is to be set when the call's LAST kernel has run (the sum kernel of an embedded pair, else the step kernel): bound to
+	// that kernel's own completion signal (hipExtLaunchKernel), not recorded behind it -- a record is a barrier packet of its own, and
+	// the next kernel of the stream starts ~7 us later for it (kernel-trace timelines, profiles/r05/ring_cycle_timeline.txt).
+	hipEvent_t done_event = nullptr;
 };
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s);

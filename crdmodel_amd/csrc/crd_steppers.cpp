@@ -209,10 +209,10 @@ int fused_launch_multi(crd_ctx *const *cs, int n, double t, double dt, int src, 
 	for (int k = 0; k < n; k++) {
 		crd_ctx *c = cs[k];
 		if (int rc = set_device(c)) return rc;
-		const FusedCall call = call_of(c, t, src, dst, nsub);
+		FusedCall call = call_of(c, t, src, dst, nsub);
+		call.done_event = c->ev_edges;  // (set by the launch's own completion: no record, no bubble in front of the interior launch)
 		if (c->nyl >= 4 * B) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, B, c->nyl - B, c->nyl, c->compute));
 		else HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, 0, c->nyl, 0, 0, c->compute));
-		HIP_TRY(c, hipEventRecord(c->ev_edges, c->compute));
 	}
 	if (int rc = exchange_stage_input(cs, n, dst, G, true)) return rc;
 	for (int k = 0; k < n; k++) {
@@ -859,15 +859,13 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			// through with the slot's device scalar before this attempt's sum lands there)
 			if (reduce_on_device) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_norm[slot], 0));
 			call.err_sum = reduce_on_device ? c->scalar_dev + kAttemptScalar + slot : c->scalar_host + kAttemptScalar + slot;  // (the sum kernel writes page-locked memory directly unless ranks still have to be added)
+			call.done_event = reduce_on_device ? c->ev_attempt[slot] : c->ev_norm[slot];  // set by the sum kernel's own completion
 			HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -e, c->nyl + e, 0, 0, c->compute));
 			if (reduce_on_device) {
-				HIP_TRY(c, hipEventRecord(c->ev_attempt[slot], c->compute));
 				HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_attempt[slot], 0));
 				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev + kAttemptScalar + slot, c->scalar_dev + kAttemptScalar + slot, 1, ncclDouble, ncclSum, c->nccl, c->comm));  // (every rank gets the same bits, hence takes the same decision)
 				HIP_TRY(c, hipMemcpyAsync(c->scalar_host + kAttemptScalar + slot, c->scalar_dev + kAttemptScalar + slot, sizeof(double), hipMemcpyDeviceToHost, c->comm));
 				HIP_TRY(c, hipEventRecord(c->ev_norm[slot], c->comm));
-			} else {
-				HIP_TRY(c, hipEventRecord(c->ev_norm[slot], c->compute));
 			}
 		}
 		ext_of[dst] = multi ? e : (1 << 20);

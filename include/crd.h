@@ -41,7 +41,7 @@ enum { CRD_PRECISION_F64 = 0, CRD_PRECISION_F32 = 1 };
 enum {
 	CRD_STEPPER_AUTO = 0,
 	CRD_STEPPER_STAGED = 1, /* four stage kernels per step, one halo row exchanged per stage */
-	CRD_STEPPER_FUSED = 2   /* one kernel per step (all four stages on chip); multi-slab: 4 E halo rows every E steps (crd_set_exchange_period, default 8); slabs shorter than that use the staged kernels */
+	CRD_STEPPER_FUSED = 2   /* one kernel per step (all four stages on chip); multi-slab: 4 E halo rows every E steps (crd_set_exchange_period); slabs shorter than that use the staged kernels */
 };
 
 /* Halo transport between the slabs of one run. */
@@ -297,7 +297,7 @@ int crd_step_rk4(crd_ctx *ctx, double t0, double dt, int64_t nsteps);
 
 /* The exchange period E of the one-launch stepper on several slabs: E steps between two halo exchanges, each of 4 E ghost rows
  * of both fields; in between every slab recomputes the shrinking ghost region redundantly (same kernel, same inputs: bit-identical
- * to what the owner computes).  3 <= E <= 16, default 8.  A property of the RUN: every context of a LOCAL group / every rank of a
+ * to what the owner computes).  3 <= E <= 16; default 16 where every slab of the run has 256 rows or more, else 8.  A property of the RUN: every context of a LOCAL group / every rank of a
  * ring must be given the same value before its next stepping call (which then starts with an exchange).  A longer period halves the
  * per-step share of a cycle's fixed cost (two small launches, two cross-stream waits) and of the exchange's latency for a few per
  * cent more redundant rows; bench.py rehearses 8 and 16 on the machine at hand.  Slabs shorter than 4 E rows step with the staged
