@@ -22,7 +22,7 @@ def test_every_plan_candidate_has_a_pmc_traffic_entry_and_a_kernel_trace_record(
     for model, precision in (("fhn", "f64"), ("goldbeter", "f64"), ("fhn", "f32")):
         for plan in plans:
             key = crd.plan_key(model, precision, plan)
-            assert key in traffic, "no rocprofv3 --pmc passes recorded for %s (tools/jobs/r04_sweep.sh)" % key
+            assert key in traffic, "no rocprofv3 --pmc passes recorded for %s (tools/jobs/r05_sweep.sh)" % key
             rec = traffic[key]
             real = 8 if precision == "f64" else 4
             # read + write of both fields once is the least a launch can move; the aprons and strip edges add to it
@@ -53,7 +53,7 @@ def test_pinned_bench_stats_reproduce_the_sweep_for_the_headline_workload():
     for plan in crd.launch_plan_candidates():
         rec = stats[crd.plan_key("fhn", "f64", plan)]
         if "bench_stats_avg_us" not in rec:
-            pytest.fail("no pinned bench.py --stats record for %s (tools/jobs/r04_plan_stats.sh)" % crd.plan_key("fhn", "f64", plan))
+            pytest.fail("no pinned bench.py --stats record for %s (tools/jobs/r05_plan_stats.sh)" % crd.plan_key("fhn", "f64", plan))
         assert rec["bench_stats_calls"] >= 100
         # (bench.py's figure is the average of a few dozen event-bracketed launches of the timed region, the profiler's of every launch
         # of the process: they agree to 2 % for most plans, 8 % at worst)

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Fold the per-plan records of tools/plan_sweep_summary.py (gpurun_out/r04/sweep/<config>.json, copied to profiles/r04/sweep/) into the
+"""Fold the per-plan records of tools/plan_sweep_summary.py (gpurun_out/r05/sweep/<config>.json, copied to profiles/r05/sweep/) into the
 two tables bench.py quotes: profiles/pmc_traffic.json (HBM bytes per grid point and launch, per plan) and profiles/plan_stats.json
 (launch durations of every plan under `rocprofv3 --kernel-trace`, plus -- when given -- the `--stats` rows of bench.py itself with
 that plan pinned).
 
-    tools/merge_plan_profiles.py profiles/r04/sweep/*.json [--bench-stats profiles/r04/plan_stats_bench.json]
+    tools/merge_plan_profiles.py profiles/r05/sweep/*.json [--bench-stats profiles/r05/plan_stats/plan_stats_bench_fhn_f64.json]
 """
 import argparse
 import json
@@ -26,7 +26,7 @@ def main():
     traffic["_comment"] = ("HBM-side bytes per grid point per launch of the dominant kernel, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes; FETCH doubled per "
                            "the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md, calibrated in profiles/r01/pmc_calibration.json).  fused/<model>/<precision>/chunk<mode>/"
                            "map<mapping>/cols<columns per lane>/<nt|plain>[/steps2]: one entry per launch plan the tuner can choose (crd_launch_plan_candidate), measured by pinning "
-                           "the plans in turn in one process (tools/plan_sweep.py, tools/jobs/r04_sweep.sh); bench.py reports the entry of the plan its run used.  A two-step launch "
+                           "the plans in turn in one process (tools/plan_sweep.py, tools/jobs/r05_sweep.sh); bench.py reports the entry of the plan its run used.  A two-step launch "
                            "(/steps2) moves its bytes once per TWO grid-point-steps.  tests/test_profiles.py fails when a candidate has no entry.")
     for path in a.sweeps:
         d = json.load(open(path))
