@@ -460,10 +460,10 @@ __device__ __forceinline__ void fused_item(const Slab<Real> &s, const FusedArgs<
 	    std::make_integer_sequence<int, PRO>{});
 	int m = PRO;
 	for (; m + M - 1 < niter; m += M)  // steady state: M iterations per trip, every register slot a compile-time constant
-		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::integral_constant<int, 4 * kApron>{}); }, std::make_integer_sequence<int, M>{});
+		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::false_type{}); }, std::make_integer_sequence<int, M>{});
 	for_sequence(
 	    [&](auto k) {
-		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::integral_constant<int, 4 * kApron>{});
+		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::false_type{});
 	    },
 	    std::make_integer_sequence<int, M - 1>{});
 	if constexpr (EMBED != 0) {
