@@ -143,6 +143,11 @@ hipError_t launch_axpy_planes(int precision, Planes y, Planes f, double h, Plane
 hipError_t launch_ydd_sumsq(int precision, Planes y, Planes f0, Planes f2, double h, double rtol, double atol, int nx, int nyl, double *partials_dev, double *out_dev,
                             hipStream_t s);
 
+// One double from device memory to page-locked, device-visible host memory by a one-thread kernel, `done` set by that kernel's own
+// completion (no record): what the host waits for after a reduction over the ranks.  (hipMemcpyAsync of 8 bytes is a blit kernel of
+// 7 - 20 us on this stack, and an event record behind it a barrier packet of its own.)
+hipError_t launch_scalar_to_host(const double *src_dev, double *dst_host_mapped, hipEvent_t done, hipStream_t s);
+
 // max |u| over the owned rows, written to *out (device double).
 hipError_t launch_max_abs(int precision, const void *u_plane, int nx, int nyl, double *out_dev, hipStream_t s);
 

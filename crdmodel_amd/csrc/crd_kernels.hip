@@ -8,6 +8,7 @@
 // neighbours of the slab's first / last row come from ghost rows (or wrap inside a single slab); the curvature
 // coefficients are per-column tables in HBM (L2-resident); no MFMA -- there is no contraction in this path.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <type_traits>
 
@@ -568,6 +569,15 @@ hipError_t launch_plane_cols_extract(int precision, const void *u_plane, void *c
 	if (precision == CRD_PRECISION_F64)
 		crd_cols_extract_kernel<double><<<g, 256, 0, s>>>(row0<double>(const_cast<void *>(u_plane), nx), static_cast<double *>(col_w), static_cast<double *>(col_e), nx, nyl, 1);
 	else crd_cols_extract_kernel<float><<<g, 256, 0, s>>>(row0<float>(const_cast<void *>(u_plane), nx), static_cast<float *>(col_w), static_cast<float *>(col_e), nx, nyl, 1);
+	return launch_status();
+}
+
+__global__ void crd_scalar_to_host_kernel(const double *__restrict__ src, double *__restrict__ dst) { *dst = *src; }
+
+hipError_t launch_scalar_to_host(const double *src_dev, double *dst_host_mapped, hipEvent_t done, hipStream_t s)
+{
+	clear_launch_status();
+	hipExtLaunchKernelGGL(crd_scalar_to_host_kernel, dim3(1), dim3(1), 0, s, nullptr, done, 0, src_dev, dst_host_mapped);
 	return launch_status();
 }
 

@@ -864,8 +864,7 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			if (reduce_on_device) {
 				HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_attempt[slot], 0));
 				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev + kAttemptScalar + slot, c->scalar_dev + kAttemptScalar + slot, 1, ncclDouble, ncclSum, c->nccl, c->comm));  // (every rank gets the same bits, hence takes the same decision)
-				HIP_TRY(c, hipMemcpyAsync(c->scalar_host + kAttemptScalar + slot, c->scalar_dev + kAttemptScalar + slot, sizeof(double), hipMemcpyDeviceToHost, c->comm));
-				HIP_TRY(c, hipEventRecord(c->ev_norm[slot], c->comm));
+				HIP_TRY(c, launch_scalar_to_host(c->scalar_dev + kAttemptScalar + slot, c->scalar_host + kAttemptScalar + slot, c->ev_norm[slot], c->comm));
 			}
 		}
 		ext_of[dst] = multi ? e : (1 << 20);
