@@ -1033,7 +1033,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		if (v >= 1 && v <= kMaxWavesPerBlock) sw = v;
 	}
 	a.sw = sw;
-	a.err_partials = c.err_partials;
+	a.err_partials = c.err_partials ? c.err_partials + c.err_offset : nullptr;
 	a.err_lo = d.wrap ? INT32_MIN : 0;
 	a.err_hi = d.wrap ? INT32_MAX : d.nyl;
 	a.rtol = (Real)c.rtol;
@@ -1090,7 +1090,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	};
 	auto fire = [&]() -> hipError_t {
 		if (c.embed) {
-			if (!c.err_partials || c.err_capacity < a.nitems || !c.err_sum) return hipErrorInvalidValue;
+			if (!c.err_partials || c.err_capacity < c.err_offset + a.nitems || !c.err_sum) return hipErrorInvalidValue;
 			auto with = [&](auto absorb_c, auto embed_c, auto nt_c) {
 				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, decltype(embed_c)::value, 1, decltype(nt_c)::value>
 				    <<<a.nblocks, block, 0, st>>>(s, a);
@@ -1105,8 +1105,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 			};
 			if (absorb1) with_nt(std::true_type{});
 			else with_nt(std::false_type{});
-			if (c.done_event) hipExtLaunchKernelGGL(crd_sum_partials_kernel, dim3(1), dim3(256), 0, st, nullptr, c.done_event, 0, (const double *)c.err_partials, a.nitems, c.err_sum);
-			else crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, a.nitems, c.err_sum);
+			if (c.err_items_out) *c.err_items_out = a.nitems;
+			if (c.err_defer_sum) return launch_status();  // (the second launch of a cut attempt sums both launches' partials)
+			if (c.done_event) hipExtLaunchKernelGGL(crd_sum_partials_kernel, dim3(1), dim3(256), 0, st, nullptr, c.done_event, 0, (const double *)c.err_partials, c.err_offset + a.nitems, c.err_sum);
+			else crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, c.err_offset + a.nitems, c.err_sum);
 		} else {
 			// plain step: absorbing rows x columns per lane x store hint x steps per launch, all compile-time
 			bool last_launch = true;  // (of this call: the one a done_event is bound to)

@@ -100,6 +100,12 @@ struct FusedCall {
 	double *err_partials = nullptr;  // device scratch, err_capacity doubles (>= fused_max_items)
 	int err_capacity = 0;
 	double *err_sum = nullptr;       // device: the sum, written by a follow-up reduction on the same stream
+	// An attempt cut into two launches (the rows that read owned rows only go under a halo exchange, the rest behind it): the first launch
+	// leaves its partials at the front and sums nothing (err_defer_sum; it says how many it wrote in *err_items_out), the second appends
+	// its own behind them (err_offset) and the one sum kernel behind it adds all of them, in that order.
+	int err_offset = 0;
+	bool err_defer_sum = false;
+	int *err_items_out = nullptr;
 	FusedPlan *plan = nullptr;       // launch plan of the context (nullptr: plain plan)
 	// A third plane set the plan measurement may overwrite: candidates are then timed stepping yout -> scratch -> yout ..., every
 	// launch reading what the previous one wrote as real stepping does, instead of repeating y0 -> yout (whose input, never
