@@ -33,6 +33,14 @@ bool fused_plan_candidate(int index, int *chunk_mode, int *mapping, int *cols, i
 	return true;
 }
 
+hipError_t launch_sum_partials(const double *partials, int n, double *out, hipEvent_t done, hipStream_t s)
+{
+	clear_launch_status();
+	if (done) hipExtLaunchKernelGGL(crd_sum_partials_kernel, dim3(1), dim3(256), 0, s, nullptr, done, 0, partials, n, out);
+	else crd_sum_partials_kernel<<<1, 256, 0, s>>>(partials, n, out);
+	return launch_status();
+}
+
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s)
 {

@@ -1092,8 +1092,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		if (c.embed) {
 			if (!c.err_partials || c.err_capacity < c.err_offset + a.nitems || !c.err_sum) return hipErrorInvalidValue;
 			auto with = [&](auto absorb_c, auto embed_c, auto nt_c) {
-				crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, decltype(embed_c)::value, 1, decltype(nt_c)::value>
-				    <<<a.nblocks, block, 0, st>>>(s, a);
+				auto kernel = crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, decltype(embed_c)::value, 1, decltype(nt_c)::value>;
+				// (the sum deferred to the caller -- another stream, launch_sum_partials: the event is this kernel's own completion)
+				if (c.err_defer_sum && c.done_event) hipExtLaunchKernelGGL(kernel, dim3(a.nblocks), block, 0, st, nullptr, c.done_event, 0, s, a);
+				else kernel<<<a.nblocks, block, 0, st>>>(s, a);
 			};
 			auto with_embed = [&](auto absorb_c, auto nt_c) {
 				if (c.embed == 2) with(absorb_c, std::integral_constant<int, 2>{}, nt_c);

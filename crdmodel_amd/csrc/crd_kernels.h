@@ -119,6 +119,9 @@ struct FusedCall {
 };
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s);
+// The fixed-order sum of an attempt's error partials (what launch_fused_step launches behind an embedded-pair kernel unless
+// FusedCall::err_defer_sum), for callers that run it on another stream; `done`: an event set by the kernel's own completion, or null.
+hipError_t launch_sum_partials(const double *partials, int n, double *out, hipEvent_t done, hipStream_t s);
 const char *fused_kernel_name(int precision, int model);
 bool fused_step_supported(int precision, const SlabDesc &d);
 int fused_default_columns(int precision, int nx);  // columns per lane of launches without a measured plan

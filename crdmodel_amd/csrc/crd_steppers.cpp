@@ -863,18 +863,26 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			call.err_partials = c->err_partials + (size_t)slot * (size_t)c->err_capacity;
 			call.err_capacity = c->err_capacity;
 			const bool reduce_on_device = c->halo == CRD_HALO_RCCL;
-			// (the slot's previous user may have been launched ahead and never waited for: its reduction on the second stream must be
-			// through with the slot's device scalar before this attempt's sum lands there)
-			// -- only then: a slot whose attempt the host has waited for (finish_attempt) is quiet, and a cross-stream wait in front of every
-			// attempt is a bubble of its own
-			if (reduce_on_device && in_flight[slot]) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_norm[slot], 0));
-			call.err_sum = reduce_on_device ? c->scalar_dev + kAttemptScalar + slot : c->scalar_host + kAttemptScalar + slot;  // (the sum kernel writes page-locked memory directly unless ranks still have to be added)
-			call.done_event = reduce_on_device ? c->ev_attempt[slot] : c->ev_norm[slot];  // set by the sum kernel's own completion
+			// (the slot's previous user may have been launched ahead and never waited for: its sum and reduction on the second stream must be
+			// through with the slot's partials and scalar before this attempt writes them -- only then: a slot whose attempt the host has
+			// waited for (finish_attempt) is quiet, and a cross-stream wait in front of every attempt is a bubble of its own)
+			if (in_flight[slot]) HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_norm[slot], 0));
+			// The sum of the partials runs on the SECOND stream behind the step kernel's own completion signal, so that the compute stream
+			// carries step kernels only, back to back: a one-block kernel between two sweeps cost its 8 us and 5 more of dispatch latency
+			// it is too short to hide (kernel-trace timelines, profiles/r05/adaptive_attempt_timeline_kernel_trace.txt).
+			// (The RK4(3) pair launches nothing ahead of a verdict: there the hop to the second stream is latency added to every attempt --
+			// 76 -> 86 us measured -- and the sum stays behind its sweep on the compute stream.)
+			const bool sum_off_stream = arkode_method;
+			double *const sum_to = reduce_on_device ? c->scalar_dev + kAttemptScalar + slot : c->scalar_host + kAttemptScalar + slot;
+			call.err_sum = sum_to;
+			call.err_defer_sum = sum_off_stream;
+			call.done_event = sum_off_stream || reduce_on_device ? c->ev_attempt[slot] : c->ev_norm[slot];
+			int items = 0, inner_items = 0;
+			call.err_items_out = &items;
 			if (under_exchange) {
 				FusedCall inner = call;
-				int inner_items = 0;
 				inner.done_event = nullptr;
-				inner.err_defer_sum = true;
+				inner.err_defer_sum = true;  // (the second launch, or the second stream, sums both launches' partials)
 				inner.err_items_out = &inner_items;
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, inner, kEmbedHalo, c->nyl - kEmbedHalo, 0, 0, c->compute));
 				HIP_TRY(c, hipStreamWaitEvent(c->compute, c->ev_halo, 0));
@@ -883,10 +891,13 @@ static int integrate_adaptive_impl(crd_ctx *const *cs, int n, double t0, double 
 			} else {
 				HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -e, c->nyl + e, 0, 0, c->compute));
 			}
+			if (sum_off_stream || reduce_on_device) HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_attempt[slot], 0));
 			if (reduce_on_device) {
-				HIP_TRY(c, hipStreamWaitEvent(c->comm, c->ev_attempt[slot], 0));
+				if (sum_off_stream) HIP_TRY(c, launch_sum_partials(call.err_partials, inner_items + items, sum_to, nullptr, c->comm));
 				NCCL_TRY(c, g_rccl.AllReduce(c->scalar_dev + kAttemptScalar + slot, c->scalar_dev + kAttemptScalar + slot, 1, ncclDouble, ncclSum, c->nccl, c->comm));  // (every rank gets the same bits, hence takes the same decision)
 				HIP_TRY(c, launch_scalar_to_host(c->scalar_dev + kAttemptScalar + slot, c->scalar_host + kAttemptScalar + slot, c->ev_norm[slot], c->comm));
+			} else if (sum_off_stream) {
+				HIP_TRY(c, launch_sum_partials(call.err_partials, inner_items + items, sum_to, c->ev_norm[slot], c->comm));  // (straight into page-locked memory)
 			}
 		}
 		ext_of[dst] = multi ? e : (1 << 20);
