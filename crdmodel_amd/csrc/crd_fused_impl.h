@@ -1113,12 +1113,14 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 			else crd_sum_partials_kernel<<<1, 256, 0, st>>>(c.err_partials, c.err_offset + a.nitems, c.err_sum);
 		} else {
 			// plain step: absorbing rows x columns per lane x store hint x steps per launch, all compile-time
-			bool last_launch = true;  // (of this call: the one a done_event is bound to)
+			bool last_launch = true, first_launch = true;  // (of this call: the ones a done_event / a start_event is bound to)
 			auto with = [&](auto absorb_c, auto cols_c, auto nt_c, auto steps_c) {
 				auto kernel = crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value,
 				                                        kCanTwoSteps ? decltype(steps_c)::value : 1>;
-				if (c.done_event && last_launch) hipExtLaunchKernelGGL(kernel, dim3(a.nblocks), block, 0, st, nullptr, c.done_event, 0, s, a);
+				hipEvent_t e0 = first_launch ? c.start_event : nullptr, e1 = last_launch ? c.done_event : nullptr;
+				if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(a.nblocks), block, 0, st, e0, e1, 0, s, a);
 				else kernel<<<a.nblocks, block, 0, st>>>(s, a);
+				first_launch = false;
 			};
 			auto with_steps = [&](auto absorb_c, auto cols_c, auto nt_c) {
 				if (steps == 2) with(absorb_c, cols_c, nt_c, std::integral_constant<int, 2>{});

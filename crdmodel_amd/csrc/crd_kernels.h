@@ -116,6 +116,9 @@ struct FusedCall {
 	// that kernel's own completion signal (hipExtLaunchKernel), not recorded behind it -- a record is a barrier packet of its own, and
 	// the next kernel of the stream starts ~7 us later for it (kernel-trace timelines, profiles/r05/ring_cycle_timeline.txt).
 	hipEvent_t done_event = nullptr;
+	// ... and one set when the call's FIRST kernel starts (hipExtLaunchKernel's start event): the pair times a launch with no record on
+	// either side of it (crd_step_rk4_timed's sampled launches).
+	hipEvent_t start_event = nullptr;
 };
 hipError_t launch_fused_step(int precision, const SlabDesc &d, const FusedCall &c, int row_begin, int row_end, int row_begin2, int row_end2,
                              hipStream_t s);
