@@ -49,13 +49,6 @@ constexpr int kMaxWavesPerBlock = 4;  // (8 strips per workgroup never measured 
 #ifndef CRD_PREFETCH_GB
 #define CRD_PREFETCH_GB 4
 #endif
-// Rows in flight per wavefront of the two-steps-per-launch pipeline: 2 (an iteration is twice the arithmetic, so two rows cover the
-// time four cover in the one-step pipeline) -- and the 8 / 16 registers less are what takes fp32 x 2 columns and fp64 x 1 column from
-// 176 to 168 VGPRs, i.e. from two to three wavefronts per SIMD: 8192^2 fp64 0.2880 -> 0.2669 ms per step, fp32 0.1442 -> 0.1361
-// (profiles/r04/two_step_tune.txt).
-#ifndef CRD_PREFETCH_TWO
-#define CRD_PREFETCH_TWO 2
-#endif
 #ifndef CRD_EMBED_SLOTS
 #define CRD_EMBED_SLOTS 6
 #endif
@@ -545,16 +538,15 @@ __device__ __forceinline__ void ring_read(unsigned lds_lane, V &u, V &v)
 template <typename Real, int COLS>
 constexpr int kRingBytes = kMaxWavesPerBlock * kRingRowsOf<typename LaneValue<Real, COLS>::type> * 2 * kLanes * COLS * (int)sizeof(Real);
 
-// TWO classical RK4 steps of the item's rows in one pass over memory (STEPS = 2; round 4): the pipeline of fused_item twice over,
-// eight stages deep -- iteration m takes row p from memory, runs stages 1..4 of step n on rows p-1 .. p-4, hands the new row p-4
+// TWO classical RK4 steps of the item's rows in one pass over memory (STEPS = 2): the pipeline of fused_item twice over, eight stages
+// deep -- iteration m takes row p (out of its LDS ring slot), runs stages 1..4 of step n on rows p-1 .. p-4, hands the new row p-4
 // to a second, identical pipeline as ITS input row, which runs stages 1..4 of step n+1 on rows p-5 .. p-8 and stores row p-8.
 // The state crosses memory once per TWO steps: 8 B (fp32) / 16 B (fp64) per grid-point-step instead of 16 / 32.  What it costs:
-// the apron is 8 columns and 8 rows a side (112 valid columns of 128 with two columns per lane; 16 fill iterations per chunk,
-// hence 64-row chunks), twice the pipeline registers (two or three wavefronts per SIMD instead of four), and the first 16
-// iterations of a chunk run every stage on rows that are not all there yet -- harmless (nothing of them is stored, and the
-// arithmetic has no traps) and cheaper than sixteen specialised prologue iterations in the instruction cache.  The launch is bound
-// by vector issue, not by memory: the VALU is busy 94 % of it (profiles/r04/sq), so what counts is instructions per useful point.
-// (Tried for that, round 4, and dropped: the BLOCK as the strip -- one apron around four wavefronts' 256 lanes, 240 valid columns
+// the apron is 8 columns and 8 rows a side (48 valid columns of 64; 112 of 128 with two columns per lane), 16 filling iterations per
+// chunk -- which run only the stages that have inputs, straight-line code in front of the loop -- and twice the pipeline registers
+// (three wavefronts per SIMD instead of four).  What bounds the launch is its memory traffic, with vector issue close behind
+// (profiles/r05/two_step_memory_path_ab.txt).
+// (Tried for fewer instructions per useful point, round 4, and dropped: the BLOCK as the strip -- one apron around four wavefronts' 256 lanes, 240 valid columns
 // instead of 4 x 48, the wavefronts' edge lanes taking their theta neighbours from the wavefront next door through LDS (written
 // one iteration ahead, double-buffered by the iteration's parity, the LDS value entering the DPP shift as its `old` operand so that
 // no instruction merges it).  Bit-identical, 20 % fewer vector instructions per point -- and slower: 0.305 ms per step at 8192^2
