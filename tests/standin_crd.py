@@ -46,6 +46,8 @@ def exchange(dist, plane, nyl, depth, rank, world):
 class Slab:
     def __init__(self, params, slab=0, n_slabs=1, device=0):
         self.params, self.slab, self.n_slabs = params, slab, n_slabs
+        if os.environ.get("STANDIN_CRASH_RANK") == str(slab) and n_slabs > 1 and os.environ.get("WORLD_SIZE"):
+            os._exit(3)  # (a rank that dies at start-up, before the roll call: its siblings sit in a gloo collective)
         self.grid = grid_of(params)
         self.js, self.je = slab_extents(self.grid.ny, slab, n_slabs)
         self.nx, self.nyl = self.grid.nx, self.je - self.js + 1

@@ -321,6 +321,23 @@ def test_bench_falls_back_to_the_local_transport_and_runs_it_on_request():
     assert d["config"]["launcher"]["fallback_reasons"] and d["config"]["launcher"]["fallback_reasons"][0].startswith("rccl: rank exit codes")
 
 
+def test_a_rank_that_dies_at_start_up_ends_the_ring_leg_at_once():
+    """Round-4 advice: the launcher used to wait for rank 0 alone -- a sibling that died at start-up left the survivors in a gloo
+    collective until their 300 s time-out, and the LOCAL leg started only after that.  It watches every rank now: the first non-zero
+    exit ends the leg, and the fallback delivers the line within seconds."""
+    import time
+
+    t0 = time.monotonic()
+    r = _run_bench(["--gpus", "3", "--size", "96", "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--crd-module", "tests.standin_crd", "--preheat-ms", "0"],
+                   extra_env={"STANDIN_CRASH_RANK": "1"}, timeout=200)
+    took = time.monotonic() - t0
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    la = d["config"]["launcher"]
+    assert d["config"]["halo"]["transport"] == "local" and la["transports_tried"] == ["rccl", "local"] and "rank exit codes" in la["fallback_reasons"][0] and "3" in la["fallback_reasons"][0]
+    assert took < 90, took
+
+
 def _run_ranks_like_torchrun(world, argv, extra_env, timeout=240):
     """`world` processes of bench.py with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set by the caller, as torch.distributed.run starts them
     (the form the driver uses for N > 1).  Returns [(returncode, stdout, stderr)] by rank."""
