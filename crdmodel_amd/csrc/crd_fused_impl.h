@@ -116,6 +116,75 @@ __device__ __forceinline__ void rhs_lane(V uC, V uS, V uN, V v, V cE, V cWn, V c
 	rhs_point<V, MODEL>(uC, from_lane_below(gE), gE, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
 }
 
+// ---- the BLOCK as the strip (two-step Goldbeter pipeline, fp64; round 5) ----------------------------------------------------------
+// The wavefronts of a block hold adjacent runs of 64 columns with ONE apron around all of them -- 240 valid columns of 256 instead of
+// 4 x 48 of 4 x 64 -- and a wavefront's edge lanes take their theta neighbour from the wavefront next door through LDS.  Every value
+// that is the centre of a later stage is published when it is formed (the lanes' 8 bytes at a per-lane address: lane 0 into its
+// wavefront's western slot, lane 63 into the eastern one, the 62 in between into a dump area -- switching them off costs two writes
+// of exec per value and measured more than the full-width write), the iteration ends with the block's barrier, and behind it the
+// reads of what the neighbours published go out -- they land while the next iteration waits for its row.  Slots are double-buffered
+// by the iteration's parity (a wavefront can be one barrier ahead of its neighbour, not two).  The neighbour's value enters the DPP
+// shift as its `old` operand (bound_ctrl off: a lane without a source keeps `old`), so no instruction merges it; the western first
+// difference of lane 0 is one subtraction more per stage-point.  Same arithmetic per point, same bits.
+// What it buys is instructions: (603 / 563) x (48 / 60) = 0.86 of the vector work per useful column; what it costs is the barrier and
+// eight LDS writes per iteration, which measured 12 - 15 % of an FHN iteration (150 vector instructions) and half that of a Goldbeter
+// one (280).  So: Goldbeter, bound by issue, runs 6 - 8 % faster (4096^2: 0.111 -> 0.102 ms per step); FHN, bound by its memory
+// traffic, does not (8192^2 0.2200 -> 0.2195; 4096^2 2 % slower) and keeps a strip per wavefront.
+// profiles/r05/block_strip_ab.txt; round 4 tried the same at 173 VGPRs -- two wavefronts per SIMD -- and lost 13 %.
+#if defined(CRD_COOP_ALL)  // (experiment switches: every fp64 one-column two-step pipeline / none)
+template <typename Real, int MODEL, int COLS>
+constexpr bool kCoop = sizeof(Real) == 8 && COLS == 1;
+#elif defined(CRD_NO_COOP)
+template <typename Real, int MODEL, int COLS>
+constexpr bool kCoop = false;
+#else
+template <typename Real, int MODEL, int COLS>
+constexpr bool kCoop = sizeof(Real) == 8 && COLS == 1 && MODEL == CRD_MODEL_GOLDBETER;
+#endif
+constexpr int kEdgeSlotBytes = 64;                                                // eight doubles: the eight quantities of an iteration
+constexpr int kEdgeParityBytes = 4 /* kMaxWavesPerBlock */ * 2 * kEdgeSlotBytes;  // [wavefront][side]
+constexpr int kEdgeBytes = 2 * kEdgeParityBytes;                                  // [parity]
+constexpr int kEdgeDumpBytes = 4 /* kMaxWavesPerBlock */ * 64 * 8 + kEdgeBytes;   // where the lanes in between drop their values (+ the largest slot offset)
+__device__ __forceinline__ double from_lane_below_old(double x, double old)
+{
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, 0x138, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double from_lane_above_old(double x, double old)
+{
+	int lo = __double2loint(x), hi = __double2hiint(x);
+	lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+	hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, 0x130, 0xf, 0xf, false);
+	return __hiloint2double(hi, lo);
+}
+// X: lane 63 holds the eastern neighbour wavefront's value of lane 0, lane 0 the western one's value of lane 63 (other lanes: anything)
+template <int MODEL>
+__device__ __forceinline__ void rhs_lane_edge(double uC, double X, double uS, double uN, double v, double cE, double cWn, double cP, double rowp, double ka4, bool zero,
+                                              double &du, double &dv)
+{
+	const double t = uC - X;  // lane 0: its western first difference
+	const double gE = from_lane_above_old(uC, X) - uC;
+	rhs_point<double, MODEL>(uC, from_lane_below_old(gE, t), gE, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
+}
+template <int OFF>
+__device__ __forceinline__ void edge_publish(unsigned pub, double val)
+{
+	asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(pub), "v"(val), "n"(OFF) : "memory");
+}
+typedef double double2r __attribute__((ext_vector_type(2)));
+constexpr unsigned long kEdgeLanes = 0x8000000000000001ul;  // exec mask: lanes 0 and 63
+// The barrier of an iteration (this wavefront's own publishes have landed: lgkmcnt(0)), and behind it the reads -- issued, not waited
+// for: ring_read_with_edges does that -- of the eight quantities the neighbours published during it: 64 B from OFF on, into lanes 0 and 63.
+template <int OFF>
+__device__ __forceinline__ void edge_exchange(unsigned con, double2r &e01, double2r &e23, double2r &e45, double2r &e67)
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_mov_b64 exec, %5\n\tds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\t"
+	             "ds_read_b128 %2, %4 offset:%8\n\tds_read_b128 %3, %4 offset:%9\n\ts_mov_b64 exec, -1"
+	             : "=&v"(e01), "=&v"(e23), "=&v"(e45), "=&v"(e67) : "v"(con), "s"(kEdgeLanes), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48) : "memory");
+}
+
 // f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a compile-time unrolled loop.
 template <typename F, int... Is>
 __device__ __forceinline__ void for_sequence(F &&f, std::integer_sequence<int, Is...>)
@@ -534,6 +603,15 @@ __device__ __forceinline__ void ring_read(unsigned lds_lane, V &u, V &v)
 		asm volatile("s_waitcnt vmcnt(%3)\n\tds_read_b128 %0, %2 offset:%4\n\tds_read_b128 %1, %2 offset:%5\n\ts_waitcnt lgkmcnt(0)"
 		             : "=&v"(u), "=&v"(v) : "v"(lds_lane), "n"(VMCNT), "n"(OFF_U), "n"(OFF_V) : "memory");
 }
+// ... and the wait covers the edge reads in flight too (edge_exchange): they pass through as operands, so that nothing uses them before it
+template <int VMCNT, int OFF_U, int OFF_V>
+__device__ __forceinline__ void ring_read_with_edges(unsigned lds_lane, double &u, double &v, double2r &e01, double2r &e23, double2r &e45, double2r &e67)
+{
+	asm volatile("s_waitcnt vmcnt(%7)\n\tds_read_b64 %0, %6 offset:%8\n\tds_read_b64 %1, %6 offset:%9\n\ts_waitcnt lgkmcnt(0)"
+	             : "=&v"(u), "=&v"(v), "+v"(e01), "+v"(e23), "+v"(e45), "+v"(e67) : "v"(lds_lane), "n"(VMCNT), "n"(OFF_U), "n"(OFF_V) : "memory");
+}
+template <int VMCNT, int OFF_U, int OFF_V, typename V>
+__device__ __forceinline__ void ring_read_with_edges(unsigned, V &, V &, double2r &, double2r &, double2r &, double2r &) {}  // (COOP is fp64, one column per lane)
 // LDS bytes of a block's rings
 template <typename Real, int COLS>
 constexpr int kRingBytes = kMaxWavesPerBlock * kRingRowsOf<typename LaneValue<Real, COLS>::type> * 2 * kLanes * COLS * (int)sizeof(Real);
@@ -546,18 +624,15 @@ constexpr int kRingBytes = kMaxWavesPerBlock * kRingRowsOf<typename LaneValue<Re
 // chunk -- which run only the stages that have inputs, straight-line code in front of the loop -- and twice the pipeline registers
 // (three wavefronts per SIMD instead of four).  What bounds the launch is its memory traffic, with vector issue close behind
 // (profiles/r05/two_step_memory_path_ab.txt).
-// (Tried for fewer instructions per useful point, round 4, and dropped: the BLOCK as the strip -- one apron around four wavefronts' 256 lanes, 240 valid columns
-// instead of 4 x 48, the wavefronts' edge lanes taking their theta neighbours from the wavefront next door through LDS (written
-// one iteration ahead, double-buffered by the iteration's parity, the LDS value entering the DPP shift as its `old` operand so that
-// no instruction merges it).  Bit-identical, 20 % fewer vector instructions per point -- and slower: 0.305 ms per step at 8192^2
-// fp64 against 0.269 (173 VGPRs: two wavefronts per SIMD; held to three, spilling, 0.342), fp32 0.60 against 0.51;
-// profiles/r04/two_step_lds_exchange_ab.txt.)
+// (Goldbeter in fp64 runs the BLOCK as the strip -- kCoop above: one apron around four wavefronts' 256 lanes, 240 valid columns.)
 // Slot arithmetic: row r of either pipeline lives in slot r mod 4; the second pipeline's rows are the first one's shifted by 4,
 // i.e. the SAME slots -- the stage code is one lambda applied to two sets of arrays.  Per point the arithmetic is the sequence of
 // two single steps exactly (same fused multiply-adds, same constants), so the result is theirs bit for bit.
 template <typename Real, int MODEL, bool ABSORB, int COLS, bool NT>
-__device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk, lds_char *const block_rings)
+__device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk, lds_char *const block_rings,
+                                                     const int sblk = 0, lds_char *const block_edges = nullptr)
 {
+	constexpr bool COOP = kCoop<Real, MODEL, COLS>;
 	using V = typename LaneValue<Real, COLS>::type;
 	constexpr int APRON = 2 * kApron;
 	static_assert(APRON % COLS == 0, "the apron is whole lanes");
@@ -573,12 +648,16 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	static_assert(kWaitSteady <= 63, "vmcnt is six bits");
 	const int lane = threadIdx.x & (kLanes - 1);
 	const int nx = s.nx;
-	int x = strip * VALID - APRON + COLS * lane;
+	// column of lane 0 (before wrapping), and this lane's place in what the apron surrounds: the wavefront's 64 lanes -- or the block's
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int x0 = COOP ? sblk * (a.sw * kLanes - 2 * APRON) - APRON + wave * kLanes : strip * VALID - APRON;
+	const int place = COOP ? wave * kLanes + lane : COLS * lane, span = COOP ? a.sw * kLanes : COLS * kLanes;
+	int x = x0 + COLS * lane;
 	x %= nx;
 	if (x < 0) x += nx;
 	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real);  // (a lane that stores has x == out_col: its column is inside [0, nx) unwrapped, so xb serves the stores too)
-	const int out_col = strip * VALID + (COLS * lane - APRON);
-	const bool lane_stores = COLS * lane >= APRON && COLS * lane < COLS * kLanes - APRON && out_col < nx;
+	const int out_col = x0 + COLS * lane;
+	const bool lane_stores = place >= APRON && place < span - APRON && out_col < nx;
 
 	const int range = chunk >= a.first2 ? 1 : 0;
 	const int range_end = a.r_end[range];
@@ -632,7 +711,17 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	B.V1[0] = B.V1[1] = B.V2[0] = B.V2[1] = B.V3[0] = B.V3[1] = zero_v;
 
 	// This wavefront's ring, and where its lanes read: lane l takes the l-th value (of sizeof(V) bytes) of a row segment.
-	lds_char *const ring = block_rings + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) * (kRingRows * SLOT);
+	lds_char *const ring = block_rings + wave * (kRingRows * SLOT);
+	// (COOP) where lanes 0 / 63 publish their values -- the wavefront's western / eastern slot -- and where they find their neighbours':
+	// lane 0 the eastern slot of the wavefront to the west, lane 63 the western slot of the one to the east (the block's outer edges:
+	// any slot, they are apron)
+	unsigned edge_pub = 0, edge_con = 0;
+	if constexpr (COOP) {
+		const unsigned base = (unsigned)(uintptr_t)block_edges;
+		edge_pub = (lane == 0 || lane == kLanes - 1) ? base + (unsigned)((wave * 2 + (lane == 0 ? 0 : 1)) * kEdgeSlotBytes)
+		                                             : base + (unsigned)(kEdgeBytes + (wave * kLanes + lane) * 8);
+		edge_con = base + (unsigned)((lane == 0 ? (wave > 0 ? wave - 1 : wave) * 2 + 1 : (wave + 1 < a.sw ? wave + 1 : wave) * 2) * kEdgeSlotBytes);
+	}
 	const unsigned ring_lane = (unsigned)(uintptr_t)ring + (unsigned)lane * (unsigned)sizeof(V);
 	// ... and what they fetch: LDS-DMA instruction h of a row moves dwords 64 h + lane of the segment; the column of a dword's
 	// element wraps periodically like x above
@@ -640,7 +729,7 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 #pragma unroll
 	for (int h = 0; h < G1; h++) {
 		const int q = 4 * (kLanes * h + lane), e = q / (int)sizeof(Real);
-		int col = (strip * VALID - APRON + e) % nx;
+		int col = (x0 + e) % nx;
 		if (col < 0) col += nx;
 		doff[h] = (unsigned)col * (unsigned)sizeof(Real) + (unsigned)(q % (int)sizeof(Real));
 	}
@@ -666,39 +755,44 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	// chunk's first sixteen iterations stage k has complete inputs only from the pipeline's iteration 2 k on -- the stages before that are
 	// skipped (their rows lie outside what the chunk's outputs depend on: nothing downstream reads what they would have written).  Half
 	// the work of those iterations, which is a tenth of a 61-row item's -- one rank's share of an 8-GPU run -- and a third of an edge band's.
-	auto stages = [&](Pipe &P, const int p, auto kk, auto live_c, const int flag_bit, const Real b4, V &nu, V &nv) {
+	[[maybe_unused]] double2r e01 = {0.0, 0.0}, e23 = {0.0, 0.0}, e45 = {0.0, 0.0}, e67 = {0.0, 0.0};  // (COOP) the neighbours' edge values, lanes 0 and 63
+	auto point = [&](V uC, V uS, V uN, V v, Real rowp, bool zero, [[maybe_unused]] V X, V &du, V &dv) {
+		if constexpr (COOP) rhs_lane_edge<MODEL>(uC, X, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
+		else rhs_lane<V, MODEL>(uC, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
+	};
+	auto stages = [&](Pipe &P, const int p, auto kk, auto live_c, const int flag_bit, const Real b4, V &nu, V &nv, [[maybe_unused]] const V (&E)[4], auto qbase_c) {
 		constexpr int K = decltype(kk)::value;
+		[[maybe_unused]] constexpr int PUB = (K & 1) * kEdgeParityBytes + decltype(qbase_c)::value * 8;
 		constexpr int live = decltype(live_c)::value;  // (compile-time: the sixteen filling iterations are sixteen pieces of straight-line code)
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M, S5 = (K + 2 * M - 5) % M;
 		V du, dv;
 		if constexpr (live >= 2) {
-			rhs_lane<V, MODEL>(P.u0[S1], P.u0[S2], P.u0[S0], P.v0[S1], cE, cWn, cP, P.bq[S1], ka4,
-			                       ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), du, dv);
+			point(P.u0[S1], P.u0[S2], P.u0[S0], P.v0[S1], P.bq[S1], ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), E[0], du, dv);
 			P.U1[S1] = stage_fma(h2, du, P.u0[S1]);
+			if constexpr (COOP) edge_publish<PUB + 8>(edge_pub, P.U1[S1]);
 			P.V1[S1 & 1] = stage_fma(h2, dv, P.v0[S1]);
 			P.aU[S1] = stage_fma(h6, du, P.u0[S1]);
 			P.aV[S1] = stage_fma(h6, dv, P.v0[S1]);
 		}
 		if constexpr (live >= 4) {
-			rhs_lane<V, MODEL>(P.U1[S2], P.U1[S3], P.U1[S1], P.V1[S2 & 1], cE, cWn, cP, P.bq[S2], ka4,
-			                       ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), du, dv);
+			point(P.U1[S2], P.U1[S3], P.U1[S1], P.V1[S2 & 1], P.bq[S2], ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), E[1], du, dv);
 			P.U2[S2] = stage_fma(h2, du, P.u0[S2]);
+			if constexpr (COOP) edge_publish<PUB + 16>(edge_pub, P.U2[S2]);
 			P.V2[S2 & 1] = stage_fma(h2, dv, P.v0[S2]);
 			P.aU[S2] = stage_fma(h3, du, P.aU[S2]);
 			P.aV[S2] = stage_fma(h3, dv, P.aV[S2]);
 		}
 		if constexpr (live >= 6) {
-			rhs_lane<V, MODEL>(P.U2[S3], P.U2[S4], P.U2[S2], P.V2[S3 & 1], cE, cWn, cP, P.bq[S3], ka4,
-			                       ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), du, dv);
+			point(P.U2[S3], P.U2[S4], P.U2[S2], P.V2[S3 & 1], P.bq[S3], ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), E[2], du, dv);
 			P.U3[S3] = stage_fma(h1, du, P.u0[S3]);
+			if constexpr (COOP) edge_publish<PUB + 24>(edge_pub, P.U3[S3]);
 			P.V3[S3 & 1] = stage_fma(h1, dv, P.v0[S3]);
 			P.aU[S3] = stage_fma(h3, du, P.aU[S3]);
 			P.aV[S3] = stage_fma(h3, dv, P.aV[S3]);
 		}
 		nu = nv = zero_v;
 		if constexpr (live >= 8) {
-			rhs_lane<V, MODEL>(P.U3[S4], P.U3[S5], P.U3[S3], P.V3[S4 & 1], cE, cWn, cP, b4, ka4,
-			                       ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), du, dv);
+			point(P.U3[S4], P.U3[S5], P.U3[S3], P.V3[S4 & 1], b4, ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), E[3], du, dv);
 			nu = stage_fma(h6, du, P.aU[S4]);
 			nv = stage_fma(h6, dv, P.aV[S4]);
 		}
@@ -717,7 +811,16 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		const Real b4a = A.bq[S4], b4b = B.bq[S4];
 		// row p out of its ring slot (filled kRingRows iterations ago) ...
 		if (m < 4 * kApron + kRingRows) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitFill) : "memory");  // (fewer operations in flight while no rows come out yet)
-		ring_read<kWaitSteady, S0 * SLOT, S0 * SLOT + RB>(ring_trip, A.u0[S0], A.v0[S0]);
+		V EA[4], EB[4];
+		if constexpr (COOP) {
+			// ... together with the neighbours' edge values, whose reads the previous iteration issued behind its barrier
+			ring_read_with_edges<kWaitSteady, S0 * SLOT, S0 * SLOT + RB>(ring_trip, A.u0[S0], A.v0[S0], e01, e23, e45, e67);
+			EA[0] = e01.x, EA[1] = e01.y, EA[2] = e23.x, EA[3] = e23.y, EB[0] = e45.x, EB[1] = e45.y, EB[2] = e67.x, EB[3] = e67.y;
+			edge_publish<(K & 1) * kEdgeParityBytes>(edge_pub, A.u0[S0]);
+		} else {
+			ring_read<kWaitSteady, S0 * SLOT, S0 * SLOT + RB>(ring_trip, A.u0[S0], A.v0[S0]);
+			EA[0] = EA[1] = EA[2] = EA[3] = EB[0] = EB[1] = EB[2] = EB[3] = zero_v;
+		}
 		A.bq[S0] = uniform(pb);
 #ifndef CRD_PROBE_NOLOAD  // (probe builds, tools/build_variant.sh: what a launch costs without its row reads / its second step / its stores)
 		fill(jn, trip_byte + S0 * SLOT);  // ... and row p + kRingRows into it
@@ -729,13 +832,14 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		nu = A.u0[S0] + (V)b4a;
 		nv = A.v0[S0] + (V)b4b;
 #else
-		stages(A, p, kk, std::integral_constant<int, (FED < 8 ? FED : 8)>{}, 0, b4a, nu, nv);  // step n: the new row p - 4 ...
+		stages(A, p, kk, std::integral_constant<int, (FED < 8 ? FED : 8)>{}, 0, b4a, nu, nv, EA, std::integral_constant<int, 0>{});  // step n: the new row p - 4 ...
 #endif
 #if !defined(CRD_PROBE_HALFMATH) && !defined(CRD_PROBE_NOMATH)
 		B.u0[S0] = nu;                            // ... is the second pipeline's newest row (same slot: rows shifted by 4)
 		B.v0[S0] = nv;
 		B.bq[S0] = b4a;
-		stages(B, p - kApron, kk, std::integral_constant<int, (FED < 8 ? 0 : FED - 8)>{}, 4, b4b, nu, nv);  // step n + 1: the new row p - 8
+		if constexpr (COOP) edge_publish<(K & 1) * kEdgeParityBytes + 32>(edge_pub, nu);
+		stages(B, p - kApron, kk, std::integral_constant<int, (FED < 8 ? 0 : FED - 8)>{}, 4, b4b, nu, nv, EB, std::integral_constant<int, 4>{});  // step n + 1: the new row p - 8
 #endif
 #ifndef CRD_PROBE_NOSTORE
 		if (m >= 4 * kApron && lane_stores) {  // rows j0 .. j1 - 1 exactly
@@ -750,6 +854,9 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 #endif
 		out_row_u += nx;
 		out_row_v += nx;
+		// (COOP) what the block's wavefronts published during this iteration is complete beyond the barrier; the reads of what the next
+		// iteration needs of it go out at once and land while that iteration waits for its row
+		if constexpr (COOP) edge_exchange<(K & 1) * kEdgeParityBytes>(edge_con, e01, e23, e45, e67);
 	};
 	auto next_trip = [&]() {
 		if constexpr (kRingRows > M) {
@@ -822,6 +929,8 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) __attribute__((amdg
 	// the row rings of a two-step launch's wavefronts (fused_item_two_steps)
 	__shared__ __attribute__((aligned(16))) char rings[STEPS == 2 ? kRingBytes<Real, COLS> : 16];
 	lds_char *const block_rings = (lds_char *)rings;
+	__shared__ __attribute__((aligned(16))) char edges[(STEPS == 2 && kCoop<Real, MODEL, COLS>) ? kEdgeBytes + kEdgeDumpBytes : 16];
+	lds_char *const block_edges = (lds_char *)edges;
 	if constexpr (ABSORB) {
 		// Does any row this chunk's pipeline touches -- [j0 - APRON, j1 + APRON) -- map to global row 0 or ny - 1?  The two are
 		// neighbours on the periodic grid: the rows contain one of them exactly when [lo, hi + 1] contains a multiple of ny.
@@ -832,14 +941,14 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) __attribute__((amdg
 		const int lo = a.js + j0 - APRON, hi1 = a.js + j1 + APRON;  // (lo > -ny and hi1 < 3 ny: a slab is at most the grid, ghost rows at most a slab)
 		const bool touches = (lo <= 0 && 0 <= hi1) || (lo <= a.ny && a.ny <= hi1) || (lo <= 2 * a.ny && 2 * a.ny <= hi1);
 		if constexpr (STEPS == 2) {
-			if (touches) fused_item_two_steps<Real, MODEL, true, COLS, NT>(s, a, strip, chunk, block_rings);
-			else fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk, block_rings);
+			if (touches) fused_item_two_steps<Real, MODEL, true, COLS, NT>(s, a, strip, chunk, block_rings, sblk, block_edges);
+			else fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk, block_rings, sblk, block_edges);
 		} else {
 			if (touches) fused_item<Real, MODEL, true, EMBED, COLS, NT>(s, a, strip, chunk);
 			else fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
 		}
 	} else if constexpr (STEPS == 2) {
-		fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk, block_rings);
+		fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk, block_rings, sblk, block_edges);
 	} else {
 		fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
 	}
@@ -1076,6 +1185,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
 		const int valid = cols * kLanes - 2 * steps * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
 		a.nstrips = (d.nx + valid - 1) / valid;
+		if (steps == 2 && cols == 1 && kCoop<Real, MODEL, 1>) {  // the block as the strip: one apron around its sw wavefronts
+			const int block_valid = sw * kLanes - 2 * steps * kApron;
+			a.nstrips = sw * ((d.nx + block_valid - 1) / block_valid);
+		}
 		plan_mode = one_round;
 		plan_remap = remap;
 		layout();
@@ -1346,6 +1459,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		g.iterations_per_trip = c.embed ? CRD_EMBED_SLOTS : 4;
 		g.lanes = kLanes;
 		g.lanes_valid = (cols * kLanes - 2 * apron) / cols;
+		if (steps == 2 && cols == 1 && kCoop<Real, MODEL, 1>) g.lanes_valid = (sw * kLanes - 2 * apron) / sw;  // the block as the strip: 60 of 64 on average
 		g.mapping = a.remap;
 		g.wave_iterations = (long)a.nstrips * ((long)(rows + rows2) + (long)a.nchunks * 2 * apron);
 		return hipSuccess;
