@@ -401,7 +401,7 @@ def run_local(args, crd, ndev, emit):
         grp.set_stepper(args.stepper)
         if args.issuing_threads and hasattr(grp, "set_threads"):
             grp.set_threads(args.issuing_threads)
-        grp.set_exchange_period(args.exchange_period or (16 if min(s.nyl for s in grp.slabs) >= 256 else 8))
+        grp.set_exchange_period(args.exchange_period or (10 if min(s.nyl for s in grp.slabs) >= 256 else 8))
         grp.upload(crd.initial_conditions(cfg))
         for s in grp.slabs:
             if args.launch_plan:
@@ -567,11 +567,11 @@ def run(args, crd, world, rank, local_rank, device_sync, emit, t_start=None):
             period = {"steps": args.exchange_period, "chosen_by": "--exchange-period"}
         elif min(crd.slab_extents(slab.grid.ny, k, world)[1] - crd.slab_extents(slab.grid.ny, k, world)[0] + 1 for k in range(world)) >= 256:
             trial = {}
-            for e in (8, 16):
+            for e in (8, 10, 16):
                 slab.set_exchange_period(e)
                 slab.step_rk4_timed(0.0, dt, 2 * e)  # (settle into the cycle)
-                trial[e] = ctl.max_float(min(slab.step_rk4_timed(0.0, dt, 64)[0] / 64 for _ in range(2)))
-            keep = 16 if trial[16] < 0.99 * trial[8] else 8
+                trial[e] = ctl.max_float(min(slab.step_rk4_timed(0.0, dt, 80)[0] / 80 for _ in range(2)))  # (80: whole cycles of each)
+            keep = min(trial, key=lambda e: trial[e] * (1.0 if e == 8 else 1.01))  # (a longer period has to win by 1 %)
             slab.set_exchange_period(keep)
             period = {"steps": keep, "chosen_by": "rehearsal", "rehearsal_device_ms_per_step_max_over_ranks": {str(k): v for k, v in trial.items()}}
         comm["exchange_period"] = period

@@ -167,10 +167,12 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	c->real_size = p->precision == CRD_PRECISION_F64 ? 8 : 4;
 	c->plane_bytes = (size_t)(c->nyl + 2 * kGhost) * (size_t)c->nx * c->real_size;
 	c->halo = n_slabs == 1 ? CRD_HALO_SELF : -1;  // multi-slab contexts must be wired before use
-	// Exchange period of a multi-slab run (crd_set_exchange_period): 16 steps where every slab of the run is at least 256 rows tall, 8
-	// otherwise -- a rule in the run's own numbers, the same on every slab.  (8192 x 1024 share through the self-ring, plan pinned:
-	// E = 8 41.5 us per step, 10 37.5, 12 37.2, 16 37.2; profiles/r05/ring_cycle_timeline.txt.)
-	if (n_slabs > 1 && d0 == 1 && c->g.ny / n_slabs >= 256) c->exchange_every = kMaxExchangeEvery;
+	// Exchange period of a multi-slab run (crd_set_exchange_period): 10 steps where every slab of the run is at least 256 rows tall, 8
+	// otherwise -- a rule in the run's own numbers, the same on every slab.  (Through the self-ring on the round's final tree, E = 4 / 6 /
+	// 8 / 10 / 12 / 16: the 8192 x 1024 share 39.4 / 40.0 / 37.6 / 37.5 / 38.1 / 38.3 us per step, the 8192 x 4096 one 131.1 / 122.4 /
+	// 121.0 / 120.0 / 121.2 / 121.7; profiles/r05/ring_overhead_periods_final_tree.txt.  Mid-round, before the cycle's small launches
+	// carried their own completion events, 8 cost 41.5 and 16 was the default.)  bench.py rehearses 8 / 10 / 16 on the run's own ring.
+	if (n_slabs > 1 && d0 == 1 && c->g.ny / n_slabs >= 256) c->exchange_every = kTallSlabExchangeEvery;
 	if (const char *e = std::getenv("CRD_AUTOTUNE"))  // 0 / 1 / 2, as crd_set_autotune
 		c->plan.autotune = c->plan_embed.autotune = c->plan_arkode.autotune = std::atoi(e) <= 0 ? 0 : (std::atoi(e) >= 2 ? 2 : 1);
 	// CRD_LAUNCH_PLAN=mode,mapping,columns,nt: what crd_set_launch_plan does, for a program one cannot change (crd_run under a profiler)

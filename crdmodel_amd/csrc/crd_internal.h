@@ -31,6 +31,7 @@ constexpr int kStepHalo = 4;
 constexpr int kMinExchangeEvery = 3;  // the multi-slab fused stepper splits the first and the last step of a cycle
 constexpr int kDefaultExchangeEvery = 8;
 constexpr int kMaxExchangeEvery = 16;
+constexpr int kTallSlabExchangeEvery = 10;  // the default where every slab has 256 rows or more (crd_create)
 // Ghost rows kept above and below every slab plane: what the longest cycle exchanges.
 constexpr int kGhost = kStepHalo * kMaxExchangeEvery;
 

@@ -106,7 +106,7 @@ typedef struct crd_run_config {
 	                                * (crd_steady_state_as_printed) */
 	double rtol, atol;        /* [Solver] rtol / atol, defaults 1e-5 / 1e-10 (src/FHNmodel_torus.cpp:197-198) */
 	int32_t exchange_period;  /* [Solver] exchangePeriod: fused steps between two halo exchanges of a multi-slab run (crd_set_exchange_period, 3 .. 16);
-	                           * 0 (default) = the driver chooses: 16 where every slab has at least 256 rows, else 8 */
+	                           * 0 (default) = the driver chooses: 10 where every slab has at least 256 rows, else 8 */
 	int32_t reserved;
 } crd_run_config;
 
@@ -297,7 +297,7 @@ int crd_step_rk4(crd_ctx *ctx, double t0, double dt, int64_t nsteps);
 
 /* The exchange period E of the one-launch stepper on several slabs: E steps between two halo exchanges, each of 4 E ghost rows
  * of both fields; in between every slab recomputes the shrinking ghost region redundantly (same kernel, same inputs: bit-identical
- * to what the owner computes).  3 <= E <= 16; default 16 where every slab of the run has 256 rows or more, else 8.  A property of the RUN: every context of a LOCAL group / every rank of a
+ * to what the owner computes).  3 <= E <= 16; default 10 where every slab of the run has 256 rows or more, else 8.  A property of the RUN: every context of a LOCAL group / every rank of a
  * ring must be given the same value before its next stepping call (which then starts with an exchange).  A longer period halves the
  * per-step share of a cycle's fixed cost (two small launches, two cross-stream waits) and of the exchange's latency for a few per
  * cent more redundant rows; bench.py rehearses 8 and 16 on the machine at hand.  Slabs shorter than 4 E rows step with the staged

@@ -19,7 +19,7 @@ exposed_ms_by_rank = {}
 if os.environ.get("STANDIN_EXPOSED"):
     exposed_ms_by_rank = {int(kv.split(":")[0]): float(kv.split(":")[1]) for kv in os.environ["STANDIN_EXPOSED"].split(",")}
 # device time per step the stand-in reports by exchange period (exercises the period rehearsal)
-ms_per_step_by_period = {8: 0.060, 16: 0.0605}
+ms_per_step_by_period = {8: 0.060, 10: 0.0597, 16: 0.0605}
 created = []  # every Slab of this process
 
 

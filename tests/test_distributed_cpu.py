@@ -271,7 +271,8 @@ def test_bench_launches_its_own_ranks(world):
     util/ShellScripts/runFHNmodelTorus.sh:6): bench.py starts its N rank processes itself -- RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set,
     before it imports torch or touches a device --, rank 0's line comes back through the parent, one line on stdout, status 0.  Here
     against the stand-in for the device context, 2 and 3 real processes over gloo; slabs of 300+ rows, so the exchange-period
-    rehearsal runs too (the stand-in reports 16 steps no faster than 8: 8 stays)."""
+    rehearsal runs too (the stand-in reports 16 steps no faster than 8 and 10 steps half a percent faster -- less than the 1 % a longer
+    period has to win by: 8 stays)."""
     size = 320 * world
     r = _run_bench(["--gpus", str(world), "--size", str(size), "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--crd-module", "tests.standin_crd"],
                    extra_env={"STANDIN_EXPOSED": "1:0.08"})
@@ -283,7 +284,7 @@ def test_bench_launches_its_own_ranks(world):
     assert d["config"]["launcher"]["transports_tried"] == ["rccl"] and d["config"]["launcher"]["fallback_reasons"] == []
     assert d["config"]["halo"]["halo_selfcheck"]["ok"] and d["config"]["halo"]["slack"]["sweeps"] == 2
     ep = d["config"]["halo"]["exchange_period"]
-    assert ep["steps"] == 8 and ep["chosen_by"] == "rehearsal" and set(ep["rehearsal_device_ms_per_step_max_over_ranks"]) == {"8", "16"}
+    assert ep["steps"] == 8 and ep["chosen_by"] == "rehearsal" and set(ep["rehearsal_device_ms_per_step_max_over_ranks"]) == {"8", "10", "16"}
     assert [q["rank"] for q in d["per_rank"]] == list(range(world))
     assert d["value"] == pytest.approx(size * size * 20 / (d["ms_per_step"] * 20e-3), rel=1e-9)
     assert 0 < d["roofline"]["frac_wall"] and d["roofline"]["plan_key"] == "fused/fhn/f64/chunk0/map2/cols1/plain"

@@ -401,7 +401,9 @@ def test_bench_line_end_to_end(gpu_device):
     assert lp["pinned"] and (lp["one_round"], lp["xcd_mapping"], lp["columns_per_lane"], lp["nontemporal_stores"]) == (0, 1, 2, 1) and "cpu_baseline" not in d
     halo = d["config"]["halo"]
     assert halo["transport"] == "rccl" and halo["rccl_comm_count"] == 1 and halo["halo_selfcheck"]["ok"] and halo["slack"]["sweeps"] in (1, 2)
-    assert len(d["per_rank"]) == 1 and d["per_rank"][0]["exchanges"] == 3 and d["per_rank"][0]["rows"] == 1024
+    # (the exchange period is rehearsed on the run's own ring -- 8, 10 or 16 steps: 20 timed steps cross the cycle boundary one to three times)
+    assert halo["exchange_period"]["chosen_by"] == "rehearsal" and halo["exchange_period"]["steps"] in (8, 10, 16)
+    assert len(d["per_rank"]) == 1 and 1 <= d["per_rank"][0]["exchanges"] <= 3 and d["per_rank"][0]["rows"] == 1024
 
     d = run("--no-cpu-baseline", "--stepper", "staged")
     assert d["roofline"]["kernel"].startswith("crd_rk4_stage_kernel") and d["roofline"]["launches_per_step"] == 2 and "staged" not in d  # (stages 2 and 3 are the launches of the dominant kernel)
