@@ -92,9 +92,9 @@ __device__ __forceinline__ V splat(double c)
 	return (V)((typename ScalarOf<V>::type)c);
 }
 
-// 1 / x for a positive, normal x well inside the exponent range (here x >= K2^2 KR^2 KA^4 = 2.6): the hardware estimate
+// 1 / x for a positive, normal x well inside the exponent range (here x >= K2^2 KR^2 KA^4 / VM3 = 5.2e-3): the hardware estimate
 // (v_rcp_f64: relative error 2^-24.4, and 3.3 times the issue cost of an fp64 FMA -- tools/rcp_probe.hip) refined by ONE Newton
-// step: relative error <= 2.2e-15 = 2^-48.7 measured over [2.6, 1e6], three orders of magnitude inside the 1e-12 parity
+// step: relative error <= 2.2e-15 = 2^-48.7 measured over [2.6, 1e6] (relative: the scale of the range does not matter), three orders of magnitude inside the 1e-12 parity
 // tolerance of a right-hand side, for 3 instructions against the 11 of the compiler's correctly rounded division (a second
 // step, CRD_RCP_NEWTON=2, brings 2^-53 for two more).
 #ifndef CRD_RCP_NEWTON
@@ -145,7 +145,7 @@ inline int kernel_model(const SlabDesc &d) { return (d.model == CRD_MODEL_GOLDBE
 // Like the second difference, a first difference of neighbouring values is exact or correct to half an ulp of u, and a uniform
 // field still diffuses to exactly zero (gE = gW = 0, d2y = 0).  The reaction terms ride the same chain: FHN's "- v" is the
 // chain's first addend, 3 u - u^3 = u (3 - u^2) is two multiply-adds, EPSILON (u + b) one with EPSILON b(j) as the row parameter:
-// 9 arithmetic instructions per FHN point (round 4: 15), Goldbeter 26 (31) -- these kernels are bound by vector issue.
+// 9 arithmetic instructions per FHN point (round 4: 15), Goldbeter 25 (31) -- these kernels are bound by vector issue.
 template <typename V, int MODEL>
 __device__ __forceinline__ void rhs_point(V uC, V gW, V gE, V uS, V uN, V v, V cE, V cWn, V cP, typename ScalarOf<V>::type rowp,
                                           typename ScalarOf<V>::type ka4, bool zero, V &du, V &dv)
@@ -163,11 +163,12 @@ __device__ __forceinline__ void rhs_point(V uC, V gW, V gE, V uS, V uN, V v, V c
 	} else {
 		// v2 = VM2 z^2 / (K2^2 + z^2), v3 = VM3 y^2 z^4 / ((KR^2 + y^2)(KA^4 + z^4)) enter both equations only through
 		// w = v2 - v3 (src/GoldbeterModel_torus.cpp:715-716: dZ = v0 + v1 b - w + kf Y - k Z, dY = w - kf Y): one quotient
-		// w = (VM2 z^2 dB - VM3 y^2 z^4 dA) / (dA dB) with dA = K2^2 + z^2, dB = (KR^2 + y^2)(KA^4 + z^4).
+		// w = (VM2 z^2 dB - y^2 z^4 dA) / (dA dB) with dA = K2^2 + z^2, dB = (KR^2 + y^2)(KA^4 + z^4) / VM3.
+		// Numerator and denominator both divided by VM3 -- it enters as the constants of ONE fused multiply-add, (KR^2 + y^2) / VM3 --
+		// which saves the product VM3 (y^2 z^4 dA): 25 arithmetic instructions per point.
 		const V z2 = uC * uC, z4 = z2 * z2, y2 = v * v;
-		const V dA = splat<V>(kGbK2 * kGbK2) + z2, dB = (splat<V>(kGbKr * kGbKr) + y2) * fmadd(z2, z2, (V)ka4);
-		const V n3 = splat<V>(kGbVm3) * ((y2 * z4) * dA);
-		const V w = fmadd(splat<V>(kGbVm2), z2 * dB, -n3) * reciprocal(dA * dB);
+		const V dA = splat<V>(kGbK2 * kGbK2) + z2, dB = fmadd(splat<V>(1.0 / kGbVm3), y2, splat<V>(kGbKr * kGbKr / kGbVm3)) * fmadd(z2, z2, (V)ka4);
+		const V w = fmadd(splat<V>(kGbVm2), z2 * dB, -((y2 * z4) * dA)) * reciprocal(dA * dB);
 		dv = fmadd(splat<V>(-kGbKf), v, w);
 		const V r = fmadd(splat<V>(-kGbK), uC, (V)rowp - dv);  // rowp = v0 + v1 b
 		du = fmadd(cWn, gW, fmadd(cE, gE, fmadd(cP, d2y, r)));
