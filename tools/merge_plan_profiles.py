@@ -4,7 +4,7 @@ two tables bench.py quotes: profiles/pmc_traffic.json (HBM bytes per grid point 
 (launch durations of every plan under `rocprofv3 --kernel-trace`, plus -- when given -- the `--stats` rows of bench.py itself with
 that plan pinned).
 
-    tools/merge_plan_profiles.py profiles/r05/sweep/*.json [--bench-stats profiles/r05/plan_stats/plan_stats_bench_fhn_f64.json]
+    tools/merge_plan_profiles.py profiles/r05/sweep/*.json [--bench-stats profiles/r05/plan_stats/plan_stats_bench_*.json]
 """
 import argparse
 import json
@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("sweeps", nargs="+")
-    ap.add_argument("--bench-stats", default="")
+    ap.add_argument("--bench-stats", nargs="*", default=[])
     a = ap.parse_args()
     tpath, spath = os.path.join(ROOT, "profiles", "pmc_traffic.json"), os.path.join(ROOT, "profiles", "plan_stats.json")
     traffic = json.load(open(tpath)) if os.path.exists(tpath) else {}
@@ -40,8 +40,8 @@ def main():
                 stats.setdefault(key, {})
                 stats[key].update({"sweep_trace_avg_us": r["trace_us"]["avg"], "sweep_trace_min_us": r["trace_us"]["min"], "sweep_trace_max_us": r["trace_us"]["max"],
                                    "sweep_launches": r["trace_us"]["launches"], "grid": d["grid"], "source": rel})
-    if a.bench_stats:
-        for key, r in json.load(open(a.bench_stats)).items():
+    for path in a.bench_stats:
+        for key, r in json.load(open(path)).items():
             stats.setdefault(key, {}).update(r)
     json.dump(traffic, open(tpath, "w"), indent=1)
     json.dump(stats, open(spath, "w"), indent=1)
