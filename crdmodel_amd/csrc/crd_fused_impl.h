@@ -633,6 +633,11 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
                                                      const int sblk = 0, lds_char *const block_edges = nullptr)
 {
 	constexpr bool COOP = kCoop<Real, MODEL, COLS>;
+#ifdef CRD_NO_SETPRIO
+	constexpr bool PRIO = false;
+#else
+	constexpr bool PRIO = sizeof(Real) == 8 && COLS == 1 && MODEL == CRD_MODEL_FHN;
+#endif
 	using V = typename LaneValue<Real, COLS>::type;
 	constexpr int APRON = 2 * kApron;
 	static_assert(APRON % COLS == 0, "the apron is whole lanes");
@@ -828,6 +833,7 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		jn = (jn < jlast) ? jn + 1 : jlast;
 		pb = brow[(p < jlast) ? p + 1 : jlast];
 		V nu, nv;
+		if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);  // (see the stores below)
 #ifdef CRD_PROBE_NOMATH  // (probe build: the launch as a copy -- its memory traffic alone)
 		nu = A.u0[S0] + (V)b4a;
 		nv = A.v0[S0] + (V)b4b;
@@ -841,6 +847,12 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		if constexpr (COOP) edge_publish<(K & 1) * kEdgeParityBytes + 32>(edge_pub, nu);
 		stages(B, p - kApron, kk, std::integral_constant<int, (FED < 8 ? 0 : FED - 8)>{}, 4, b4b, nu, nv, EB, std::integral_constant<int, 4>{});  // step n + 1: the new row p - 8
 #endif
+		// (FHN fp64) From its stores to the next row's fill a wavefront issues ahead of its SIMD's other wavefronts (which are in their
+		// arithmetic): its memory operations go out when it reaches them instead of waiting their turn among vector instructions.
+		// Nothing on 8192^2, -1 % on 4096^2, -2 % on a rank's 8192 x 1024 share; 1 - 2 % SLOWER in fp32 and 0 - 1 % in Goldbeter, which
+		// do without (profiles/r05/two_step_memory_path_ab.txt, K).  Non-temporal row LOADS, tried beside it, cost 15 %: the rows' reuse
+		// by the neighbouring items is what keeps the traffic at 1.06 x compulsory.
+		if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
 #ifndef CRD_PROBE_NOSTORE
 		if (m >= 4 * kApron && lane_stores) {  // rows j0 .. j1 - 1 exactly
 			buffer_row_store<NT>(row_resource(out_row_u), xb, nu);
