@@ -545,8 +545,8 @@ def run(args, crd, world, rank, local_rank, device_sync, emit, t_start=None):
 
     # REHEARSALS (ring runs with the one-launch stepper).  Slack: three exchange cycles with per-exchange event pairs; if on ANY rank the
     # compute stream stood at its wait for a halo for longer than a queue latency, every rank gives the exchange a third sweep of cover
-    # (crd_set_halo_slack; same bits).  Period: 8 and 16 steps per exchange stepped for four cycles of the longer one, twice; the faster
-    # (MAX over ranks of each rank's best) is kept if it wins by > 1 %.  Both go to the top level of config.halo.
+    # (crd_set_halo_slack; same bits).  Period: 8, 10 and 16 steps per exchange, 80 steps each (whole cycles of all three), twice; the fastest
+    # (MAX over ranks of each rank's best) is kept, a longer period than 8 only if it wins by > 1 %.  Both go to the top level of config.halo.
     if transport == "rccl" and will_fuse:
         def rehearse():
             slab.set_diagnostics(True)
