@@ -461,7 +461,8 @@ typedef struct crd_launch_geometry {
 	int32_t workgroups, wavefronts_per_workgroup;
 	int32_t fill_iterations;           /* pipeline iterations an item runs beyond its rows (the aprons in phi) */
 	int32_t iterations_per_trip;       /* pipeline iterations one trip of the steady-state loop holds (its unroll factor) */
-	int32_t lanes, lanes_valid;        /* lanes of a wavefront / lanes whose column is an output */
+	int32_t lanes, lanes_valid;        /* lanes of a wavefront / lanes whose column is an output (kernels that put one apron around a
+	                                    * workgroup's wavefronts -- Goldbeter fp64, two steps per launch -- : the workgroup's average, 60) */
 	int32_t vgprs, sgprs, lds_bytes, scratch_bytes, wavefronts_per_simd; /* of the instantiation; 0: the build carries no kernel table */
 	int32_t loop_valu, loop_salu, loop_vmem, loop_lds, loop_instructions; /* static instruction mix of one trip of that loop */
 	int32_t simds, clock_khz;          /* of the device: 4 x compute units, hipDeviceProp_t::clockRate */
