@@ -92,6 +92,19 @@ __device__ __forceinline__ V splat(double c)
 	return (V)((typename ScalarOf<V>::type)c);
 }
 
+// A constant held in vector registers.  A VOP3 instruction reads at most ONE scalar operand: fma(constant, x, row parameter) with both
+// in scalar registers costs a v_mov of one of them in front of every use -- one vector instruction in 17.5 per FHN stage-point.  The
+// empty asm makes the value opaque (it cannot be rematerialised as a scalar) and, not being volatile, is hoisted out of the loops: one
+// register pair for the whole kernel.
+template <typename V>
+__device__ __forceinline__ V in_vector_registers(V x)
+{
+#ifndef CRD_NO_VECTOR_CONSTANTS  // (experiment switch)
+	asm("" : "+v"(x));
+#endif
+	return x;
+}
+
 // 1 / x for a positive, normal x well inside the exponent range (here x >= K2^2 KR^2 KA^4 / VM3 = 5.2e-3): the hardware estimate
 // (v_rcp_f64: relative error 2^-24.4, and 3.3 times the issue cost of an fp64 FMA -- tools/rcp_probe.hip) refined by ONE Newton
 // step: relative error <= 2.2e-15 = 2^-48.7 measured over [2.6, 1e6] (relative: the scale of the range does not matter), three orders of magnitude inside the 1e-12 parity
@@ -159,7 +172,7 @@ __device__ __forceinline__ void rhs_point(V uC, V gW, V gE, V uS, V uN, V v, V c
 	} else if (MODEL == CRD_MODEL_FHN) {
 		const V r = fmadd(cWn, gW, fmadd(cE, gE, fmadd(cP, d2y, -v)));  // diffusion - v
 		du = fmadd(uC, fmadd(-uC, uC, splat<V>(3.0)), r);               // + u (3 - u^2)
-		dv = fmadd(splat<V>(kFhnEpsilon), uC, (V)rowp);                 // rowp = EPSILON b
+		dv = fmadd(in_vector_registers(splat<V>(kFhnEpsilon)), uC, (V)rowp);  // rowp = EPSILON b
 	} else {
 		// v2 = VM2 z^2 / (K2^2 + z^2), v3 = VM3 y^2 z^4 / ((KR^2 + y^2)(KA^4 + z^4)) enter both equations only through
 		// w = v2 - v3 (src/GoldbeterModel_torus.cpp:715-716: dZ = v0 + v1 b - w + kf Y - k Z, dY = w - kf Y): one quotient
