@@ -12,7 +12,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 # CRD_LIBRARY points the binding at another build of the same ABI (tuning builds under tools/); default is the in-tree library.
 LIB_PATH = os.environ.get("CRD_LIBRARY") or os.path.join(_PKG, "libcrd.so")
 
-ABI_VERSION = 5  # CRD_ABI_VERSION of include/crd.h (tests/test_host_abi.py keeps the two in step)
+ABI_VERSION = 6  # CRD_ABI_VERSION of include/crd.h (tests/test_host_abi.py keeps the two in step)
 OK, EINVAL, ENOMEM, EHIP, ERCCL, EIO, EPARSE, ESTATE = 0, -1, -2, -3, -4, -5, -6, -7
 MODEL_FHN, MODEL_GOLDBETER = 0, 1
 SURFACE_TORUS, SURFACE_FLAT = 0, 1
@@ -101,7 +101,7 @@ class LaunchGeometry(C.Structure):
 
     _fields_ = [(f, C.c_int32) for f in ("rows", "strips", "chunk_rows", "chunks", "workgroups", "wavefronts_per_workgroup", "fill_iterations", "iterations_per_trip",
                                          "lanes", "lanes_valid", "vgprs", "sgprs", "lds_bytes", "scratch_bytes", "wavefronts_per_simd", "loop_valu", "loop_salu",
-                                         "loop_vmem", "loop_lds", "loop_instructions", "simds", "clock_khz", "reserved")] + [("wavefront_iterations", C.c_int64), ("wavefront_iterations_effective", C.c_int64)]
+                                         "loop_vmem", "loop_lds", "loop_instructions", "simds", "clock_khz", "exec_skipped_vmem")] + [("wavefront_iterations", C.c_int64), ("wavefront_iterations_effective", C.c_int64)]
 
 
 class StepTiming(C.Structure):
@@ -117,6 +117,7 @@ _vp = C.c_void_p
 _SIGNATURES = {
     "crd_abi_version": (C.c_int, []),
     "crd_status_string": (C.c_char_p, [C.c_int]),
+    "crd_kernel_table_digest": (C.c_char_p, []),
     "crd_config_load_ini": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.POINTER(RunConfig), C.c_char_p, C.c_size_t]),
     "crd_grid_from_params": (C.c_int, [C.POINTER(Params), C.POINTER(Grid)]),
     "crd_slab_extents": (C.c_int, [C.c_int64, C.c_int, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),

@@ -774,6 +774,7 @@ int crd_get_launch_geometry(crd_ctx *c, crd_launch_geometry *out)
 		out->loop_vmem = k->loop_vmem;
 		out->loop_lds = k->loop_lds;
 		out->loop_instructions = k->loop_total;
+		out->exec_skipped_vmem = k->exec_skipped_vmem;
 	}
 	hipDeviceProp_t prop;
 	HIP_TRY(c, hipGetDeviceProperties(&prop, c->device));

@@ -574,10 +574,12 @@ constexpr int kRingRowsOf = (kLanes * (int)sizeof(V) / 256 >= 4 && kRingRowsWant
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
+constexpr unsigned kRowResourceBytes = 0x7fffffffu;  // num_records of a row's buffer resource
+constexpr unsigned kStoreNowhere = 0x80000000u;      // a byte offset out of its range: the hardware drops the write
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t row_resource(const void *row)
 {
 	// raw buffer (stride 0) over the bytes from `row` on: offsets are a lane's byte offset within its row (< 2 GiB)
-	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(row), 0, 0x7fffffff, 0x00020000);
+	return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(row), 0, (int)kRowResourceBytes, 0x00020000);
 }
 template <bool NT, typename V>
 __device__ __forceinline__ void buffer_row_store(__amdgpu_buffer_rsrc_t r, unsigned byte_offset, V v)
@@ -663,6 +665,9 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	const unsigned xb = (unsigned)x * (unsigned)sizeof(Real);  // (a lane that stores has x == out_col: its column is inside [0, nx) unwrapped, so xb serves the stores too)
 	const int out_col = x0 + COLS * lane;
 	const bool lane_stores = place >= APRON && place < span - APRON && out_col < nx;
+	// ... and where its stores go: its column's bytes, or beyond the range of the row's buffer resource (row_resource: 0x7fffffff bytes),
+	// where a write is dropped -- the store instructions themselves are issued by every lane (see the stores below)
+	const unsigned xb_store = lane_stores ? xb : kStoreNowhere;
 
 	const int range = chunk >= a.first2 ? 1 : 0;
 	const int range_end = a.r_end[range];
@@ -853,17 +858,22 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		// do without (profiles/r05/two_step_memory_path_ab.txt, K).  Non-temporal row LOADS, tried beside it, cost 15 %: the rows' reuse
 		// by the neighbouring items is what keeps the traffic at 1.06 x compulsory.
 		if constexpr (PRIO) __builtin_amdgcn_s_setprio(2);
+		// Rows j0 .. j1 - 1 exactly: every iteration behind the filling ones.  BOTH store instructions go out in every such iteration of
+		// every wavefront, with all lanes on -- the waits of ring_read COUNT them (kWaitSteady).  A lane that has nothing to store (apron,
+		// or a column beyond nx) is parked on an offset beyond the buffer resource's range, where the hardware drops its write; under an
+		// `if (lane_stores)` the compiler puts a skip branch (s_cbranch_execz) in front of the stores, a wavefront without a storing lane
+		// then has fewer operations in flight than the wait assumes, and its ring read can overtake the LDS-DMA fill of its slot.
+		if constexpr (FED >= 4 * kApron) {
 #ifndef CRD_PROBE_NOSTORE
-		if (m >= 4 * kApron && lane_stores) {  // rows j0 .. j1 - 1 exactly
-			buffer_row_store<NT>(row_resource(out_row_u), xb, nu);
-			buffer_row_store<NT>(row_resource(out_row_v), xb, nv);
-		}
+			buffer_row_store<NT>(row_resource(out_row_u), xb_store, nu);
+			buffer_row_store<NT>(row_resource(out_row_v), xb_store, nv);
 #else
-		if (m >= 4 * kApron && lane_stores && a.nchunks < 0) {  // (never: keeps the arithmetic alive)
-			buffer_row_store<NT>(row_resource(out_row_u), xb, nu);
-			buffer_row_store<NT>(row_resource(out_row_v), xb, nv);
-		}
+			if (a.nchunks < 0) {  // (never: keeps the arithmetic alive)
+				buffer_row_store<NT>(row_resource(out_row_u), xb_store, nu);
+				buffer_row_store<NT>(row_resource(out_row_v), xb_store, nv);
+			}
 #endif
+		}
 		out_row_u += nx;
 		out_row_v += nx;
 		// (COOP) what the block's wavefronts published during this iteration is complete beyond the barrier; the reads of what the next

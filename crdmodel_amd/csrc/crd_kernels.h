@@ -84,8 +84,10 @@ struct FusedGeometry {
 // registers, occupancy, and the static instruction mix of one trip of the steady-state loop.
 struct KernelStats {
 	int real_bytes, model, absorb, embed, cols, nt, steps, vgprs, sgprs, lds_bytes, scratch_bytes, wavefronts_per_simd, loop_valu, loop_salu, loop_vmem, loop_lds, loop_total;
+	int exec_skipped_vmem;  // vector-memory regions a wavefront can skip on its execution mask (multi-step kernels: 0, or the build stops)
 };
 const KernelStats *step_kernel_stats(int real_bytes, int model, int absorb, int embed, int cols, int nt, int steps);  // nullptr: the build has no table
+const char *step_kernel_table_digest();  // 16 hex digits over the table's rows ("" without a table): the build the profile tables are stamped with
 
 struct FusedCall {
 	double dt;

@@ -20,7 +20,7 @@
 extern "C" {
 #endif
 
-#define CRD_ABI_VERSION 5
+#define CRD_ABI_VERSION 6
 
 typedef enum crd_status {
 	CRD_OK = 0,
@@ -118,6 +118,11 @@ typedef struct crd_ctx crd_ctx;
 
 int crd_abi_version(void);
 const char *crd_status_string(int status);
+/* 16 hex digits over the step kernels of THIS build as the assembler printed them (template arguments, registers, occupancy, the
+ * steady-state loop's instruction mix: tools/kernel_regs.py writes them into the library when it is built); "" for a build without the
+ * table.  The profile tables a run quotes counters from (profiles/pmc_traffic.json, plan_stats.json) carry the digest of the build they
+ * were measured on; bench.py quotes them only when it equals this one.  No reference counterpart. */
+const char *crd_kernel_table_digest(void);
 
 /* Replaces boost::property_tree::ini_parser::read_ini + the pt.get<T>() block of main()
  * (src/FHNmodel_torus.cpp:158-174 and the three siblings).  The program's own mesh key is preferred
@@ -466,7 +471,10 @@ typedef struct crd_launch_geometry {
 	int32_t vgprs, sgprs, lds_bytes, scratch_bytes, wavefronts_per_simd; /* of the instantiation; 0: the build carries no kernel table */
 	int32_t loop_valu, loop_salu, loop_vmem, loop_lds, loop_instructions; /* static instruction mix of one trip of that loop */
 	int32_t simds, clock_khz;          /* of the device: 4 x compute units, hipDeviceProp_t::clockRate */
-	int32_t reserved;
+	int32_t exec_skipped_vmem;         /* vector-memory regions of that kernel a wavefront can skip on its execution mask (device assembly,
+	                                    * tools/kernel_regs.py).  The multi-step kernels wait for their LDS-DMA row fills with hand-counted
+	                                    * s_waitcnt vmcnt(N); N counts the iteration's stores, which therefore must issue whatever the mask:
+	                                    * 0 for every such kernel, or the build stops */
 	int64_t wavefront_iterations;      /* pipeline iterations all wavefronts of the launch run: strips x (rows + chunks x fill_iterations) */
 	int64_t wavefront_iterations_effective; /* ... with an item's filling iterations at what they cost: stage k of the pipeline starts at
 	                                    * iteration 2 k, so the fill runs fill_iterations / 2 - 1 iterations' worth of stages */

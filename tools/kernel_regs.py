@@ -49,6 +49,41 @@ def classify(op):
     return "other"
 
 
+VMEM_OP = re.compile(r"\s*(buffer_|global_|flat_|scratch_)")
+
+
+def exec_skipped_vmem(body):
+    """Vector-memory instructions a wavefront can SKIP on its execution mask: [(line, branch, first skipped instruction)].
+
+    The multi-step pipelines wait for their LDS-DMA row fills with hand-counted `s_waitcnt vmcnt(N)` (crd_fused_impl.h: ring_read,
+    kWaitFill / kWaitSteady): N is the number of vector-memory operations the wavefront ISSUES between a slot's fill and its read.
+    The count must not depend on the execution mask: a `s_cbranch_execz` that jumps over a store (what the compiler forms around
+    `if (lane_stores) store`) leaves a wavefront without storing lanes with fewer operations in flight than N, the wait then waits
+    for nothing and the read can overtake the fill.  A region skipped as a whole is harmless when it drains what it issued
+    (`s_waitcnt vmcnt(0)` behind its last vector-memory instruction: the whole work item under the per-chunk absorbing-rows
+    decision is such a region)."""
+    label_at = {}
+    for k, ln in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            label_at[m.group(1)] = k
+    found = []
+    for k, ln in enumerate(body):
+        m = re.match(r"\s*s_cbranch_exec(?:z|nz)\s+(\S+)", ln)
+        if not m:
+            continue
+        t = label_at.get(m.group(1))
+        if t is None or t <= k:
+            continue  # a loop's back edge: nothing is skipped
+        vm = [q for q in range(k + 1, t) if VMEM_OP.match(body[q])]
+        if not vm:
+            continue
+        if any(re.match(r"\s*s_waitcnt\s+vmcnt\(0\)", body[q]) for q in range(vm[-1] + 1, t)):
+            continue
+        found.append((k, ln.strip(), body[vm[0]].strip()))
+    return found
+
+
 def parse(text):
     """[{name (mangled), vgprs, sgprs, scratch, occupancy, lds, loop: {valu, salu, vmem, lds, other, total}}] for every kernel."""
     kernels = []
@@ -87,11 +122,21 @@ def parse(text):
             mix["total"] = sum(mix.values())
             if best is None or mix["valu"] > best["valu"]:
                 best = mix
-        kernels.append({"mangled": name, "vgprs": meta.get("NumVgprs", 0), "sgprs": meta.get("TotalNumSgprs", meta.get("NumSgprs", 0)), "scratch": meta.get("ScratchSize", 0),
+        kernels.append({"mangled": name, "exec_skipped_vmem": len(exec_skipped_vmem(body)), "vgprs": meta.get("NumVgprs", 0), "sgprs": meta.get("TotalNumSgprs", meta.get("NumSgprs", 0)), "scratch": meta.get("ScratchSize", 0),
                         "occupancy": meta.get("Occupancy", 0), "lds": meta.get("LDSByteSize", 0), "loop": best or {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0, "total": 0}})
     for k, nm in zip(kernels, demangle([k["mangled"] for k in kernels])):
         k["name"] = nm
     return kernels
+
+
+def table_digest(rows):
+    """16 hex digits over the step kernels' rows (template arguments, registers, occupancy, loop instruction mix): two builds whose
+    kernels the assembler printed alike have the same digest; a changed kernel changes it.  Profile tables (profiles/pmc_traffic.json,
+    plan_stats.json) carry the digest of the build they were measured on."""
+    import hashlib
+
+    canon = json.dumps(sorted(rows, key=lambda r: (r["precision"], r["model"], r["absorb"], r["embed"], r["cols"], r["nt"], r["steps"])), sort_keys=True)
+    return hashlib.sha256(canon.encode()).hexdigest()[:16]
 
 
 STEP_KERNEL = re.compile(r"crd_rk4_fused_step_kernel<(double|float), (\d+), (true|false), (\d+), (\d+), (true|false), (\d+)>")
@@ -109,11 +154,12 @@ def main():
         kernels += parse(compile_to_asm(a.source, extra))
     for path in a.asm:
         kernels += parse(open(path).read())
-    print("%-64s %5s %5s %7s %4s %6s | loop: %5s %5s %5s %4s %6s" % ("kernel", "VGPR", "SGPR", "scratch", "occ", "LDS", "VALU", "SALU", "VMEM", "LDS", "total"))
+    print("%-64s %5s %5s %7s %4s %6s | loop: %5s %5s %5s %4s %6s | %s" % ("kernel", "VGPR", "SGPR", "scratch", "occ", "LDS", "VALU", "SALU", "VMEM", "LDS", "total",
+                                                                         "exec-skipped VMEM"))
     for k in kernels:
         lp = k["loop"]
-        print("%-64s %5d %5d %7d %4d %6d | %11d %5d %5d %4d %6d" % (k["name"][:64], k["vgprs"], k["sgprs"], k["scratch"], k["occupancy"], k["lds"], lp["valu"], lp["salu"],
-                                                                     lp["vmem"], lp["lds"], lp["total"]))
+        print("%-64s %5d %5d %7d %4d %6d | %11d %5d %5d %4d %6d | %d" % (k["name"][:64], k["vgprs"], k["sgprs"], k["scratch"], k["occupancy"], k["lds"], lp["valu"], lp["salu"],
+                                                                          lp["vmem"], lp["lds"], lp["total"], k["exec_skipped_vmem"]))
     rows = []
     for k in kernels:
         m = STEP_KERNEL.search(k["name"])
@@ -121,18 +167,29 @@ def main():
             real, model, absorb, embed, cols, nt, steps = m.groups()
             rows.append({"precision": "f64" if real == "double" else "f32", "model": int(model), "absorb": int(absorb == "true"), "embed": int(embed), "cols": int(cols),
                          "nt": int(nt == "true"), "steps": int(steps), "vgprs": k["vgprs"], "sgprs": k["sgprs"], "lds_bytes": k["lds"], "scratch_bytes": k["scratch"],
-                         "wavefronts_per_simd": k["occupancy"], "loop": k["loop"]})
+                         "wavefronts_per_simd": k["occupancy"], "loop": k["loop"], "exec_skipped_vmem": k["exec_skipped_vmem"]})
     if a.table:
         with open(a.table, "w") as f:
             f.write("// generated by tools/kernel_regs.py from the assembly of this build's step kernels -- do not edit\n")
             for r in rows:
                 lp = r["loop"]
-                f.write("{%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},\n" % (
+                f.write("{%d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d, %d},\n" % (
                     8 if r["precision"] == "f64" else 4, r["model"], r["absorb"], r["embed"], r["cols"], r["nt"], r["steps"], r["vgprs"], r["sgprs"], r["lds_bytes"],
-                    r["scratch_bytes"], r["wavefronts_per_simd"], lp["valu"], lp["salu"], lp["vmem"], lp["lds"], lp["total"]))
+                    r["scratch_bytes"], r["wavefronts_per_simd"], lp["valu"], lp["salu"], lp["vmem"], lp["lds"], lp["total"], r["exec_skipped_vmem"]))
+            # the digest of the rows above: what profiles/*.json entries are stamped with (crd_kernel_table_digest, bench.py)
+            f.write("#define CRD_KERNEL_TABLE_DIGEST \"%s\"\n" % table_digest(rows))
     if a.json:
-        json.dump({"_comment": "step kernels of this build: registers, occupancy and the static instruction mix of the steady-state loop (one trip = the unrolled "
+        json.dump({"digest": table_digest(rows), "_comment": "step kernels of this build: registers, occupancy and the static instruction mix of the steady-state loop (one trip = the unrolled "
                                "pipeline iterations), from the code object's assembly (tools/kernel_regs.py)", "kernels": rows}, open(a.json, "w"), indent=1)
+
+
+    # The vmcnt contract of the multi-step pipelines (exec_skipped_vmem above): a build that breaks it does not go on.
+    broken = [r for r in rows if r["steps"] >= 2 and r["exec_skipped_vmem"]]
+    for r in broken:
+        sys.stderr.write("kernel_regs.py: %s model %d absorb %d cols %d nt %d steps %d: %d vector-memory region(s) skipped on the execution mask -- the hand-counted "
+                         "s_waitcnt vmcnt of its ring reads no longer holds\n" % (r["precision"], r["model"], r["absorb"], r["cols"], r["nt"], r["steps"], r["exec_skipped_vmem"]))
+    if broken:
+        sys.exit(3)
 
 
 if __name__ == "__main__":
