@@ -40,7 +40,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-from crdmodel_amd.benchkit import ControlPlane, committed_json, halo_selfcheck, measured_traffic, selfcheck_ghost_rows, selfcheck_pattern, usable_cores  # noqa: E402,F401 (no GPU, no libcrd yet)
+from crdmodel_amd.benchkit import ControlPlane, committed_json, halo_selfcheck, measured_traffic, selfcheck_ghost_rows, selfcheck_pattern, stale_reason, usable_cores  # noqa: E402,F401 (no GPU, no libcrd yet)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 REALS_PER_POINT_STEP = 32  # 6 (stage 1) + 10 + 10 (stages 2, 3) + 6 (stage 4) reals per grid-point-step, staged scheme
@@ -70,13 +70,15 @@ def parse(argv=None):
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "local"], help="N > 1: rccl = one rank process per GPU; local = one process, LOCAL group; auto = rccl, then local")
     ap.add_argument("--ring-timeout-s", type=float, default=150.0, help="a rank stops waiting for the RCCL ring's bring-up after this long (0 = wait for ever)")
     ap.add_argument("--launch-timeout-s", type=float, default=420.0, help="time budget of ALL legs of an N > 1 run together (a healthy 8-rank run takes about a minute)")
-    ap.add_argument("--exchange-period", type=int, default=0, help="ring runs: fused steps per deep-halo exchange; 0 = rehearse 8 and 16, keep the faster")
+    ap.add_argument("--exchange-period", type=int, default=0, help="ring runs: fused steps per deep-halo exchange; 0 = rehearse 8, 10 and 16, keep the fastest")
     ap.add_argument("--devices", default="", help="--transport local: device ordinal of each slab, e.g. 0,0 to rehearse two slabs on one GPU (default 0..N-1)")
     ap.add_argument("--issuing-threads", type=int, default=0, help="--transport local: host threads issuing the group's work (0 = one per device)")
     ap.add_argument("--crd-module", default="crdmodel_amd", help=argparse.SUPPRESS)  # tests: a stand-in for the device API (tests/standin_crd.py)
     ap.add_argument("--repeats", type=int, default=4, help="the K timed steps again, this many times, AFTER the timed region (spread of the figure; not part of `value`)")
     ap.add_argument("--one-step-steps", type=int, default=40, help="steps of the one-step-per-launch kernel timed beside a two-step run (0 = skip)")
     ap.add_argument("--staged-steps", type=int, default=40, help="steps of the staged stepper timed beside a fused run for the `staged` sub-record (0 = skip)")
+    ap.add_argument("--preflight", action="store_true", help="N ranks: roll call, RCCL ring bring-up, communicator self-report and the 32-row halo self-check ONLY; one JSON "
+                                                             "line ({\"preflight\": true, \"ok\": ...}) within a minute -- why a multi-GPU run would fail, without running it")
     return ap.parse_args(argv)
 
 
@@ -193,6 +195,16 @@ def launch(args, argv):
     argv = without_transport(sys.argv[1:] if argv is None else list(argv))
     deadline = time.monotonic() + args.launch_timeout_s
     tried, reasons, line, rc = [], [], None, 1
+    if args.preflight:
+        # the ring's leg alone, a minute at most, and a line either way: rank 0's on success, ours with the reason otherwise
+        t0 = time.monotonic()
+        line, why = ring_leg(args, argv, t0 + min(60.0, args.launch_timeout_s))
+        if line is None:
+            line = {"preflight": True, "ok": False, "n_gpus": args.gpus, "reasons": [why], "elapsed_s": round(time.monotonic() - t0, 2)}
+        line["launcher"] = "self-launched: %d rank process(es) started by bench.py itself" % args.gpus
+        sys.stdout.write(json.dumps(line) + "\n")
+        sys.stdout.flush()
+        return 0 if line.get("ok") else 1
     if args.transport in ("auto", "rccl"):
         tried.append("rccl")
         line, why = ring_leg(args, argv, deadline - (60.0 if args.transport == "auto" else 0.0))  # (auto: the LOCAL leg keeps a minute of the budget at least)
@@ -219,6 +231,15 @@ def ring_failed(args, ctl, slab, rank, world, failures, stuck, emit, t_start):
     rank leaves with status 4.  An external launcher with --transport auto: ranks 1.. leave with status 0, rank 0 runs the LOCAL LEG in a
     child and passes its line on.  A rank whose bring-up thread is stuck inside RCCL cannot tear anything down: it leaves through os._exit."""
     why = "; ".join(failures)
+    if args.preflight:
+        if rank == 0:
+            emit(json.dumps({"preflight": True, "ok": False, "n_gpus": world, "reasons": failures, "elapsed_s": round(time.monotonic() - t_start, 2)}))
+        if not stuck:
+            slab.close()
+        ctl.close()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(4) if stuck else sys.exit(4)
     relay = args.transport == "auto" and not os.environ.get("CRD_BENCH_SELF_LAUNCHED")
     if not stuck:
         slab.close()
@@ -323,11 +344,15 @@ def build_line(args, crd, world, dt, beta, elapsed, kernel, kernel_ms, launches,
         plan["pinned"] = True  # (--launch-plan: nothing was measured in this run)
     key = crd.plan_key(args.model, args.precision, plan) if fused else "stage23/%s/%s" % (args.model, args.precision)
     per_launch = (per_launch or int(plan.get("steps_per_launch", 1))) if fused else 1  # steps the TIMED launches advanced (crd_step_timing)
-    traffic, traffic_source = measured_traffic(key, pts_launch)
+    # the committed profiler records are quoted only for the kernel they were measured on: every entry carries the digest of its kernel
+    # (registers and loop instruction mix as the assembler printed them), compared with the loaded library's (crd_get_launch_geometry)
+    digest = crd.kernel_digest(geometry) if (fused and geometry is not None and hasattr(crd, "kernel_digest")) else None
+    traffic, traffic_source = measured_traffic(key, pts_launch, digest)
     if fused:
         reals_launch = 4
         bytes_model = ("fused step kernel (all RK4 stages of a step in one launch): compulsory bytes per launch = read + write of both fields once = 4 reals per "
-                       "point (%d B) x the points the launch covers%s" % (4 * real, "; this launch advances its points by TWO steps (%d B per grid-point-step)" % (2 * real) if per_launch == 2 else ""))
+                       "point (%d B) x the points the launch covers%s" % (4 * real, "; this launch advances its points by %s steps (%.1f B per grid-point-step)"
+                                                                           % ({2: "TWO", 3: "THREE"}.get(per_launch, str(per_launch)), 4.0 * real / per_launch) if per_launch >= 2 else ""))
     else:
         reals_launch = REALS_PER_POINT_STAGE23
         bytes_model = ("stage-2/3 kernel of the staged stepper: reads y_stage, y_n, acc and writes acc, y_next = 10 reals per point (%d B), SURVEY 8(d); a whole "
@@ -347,24 +372,35 @@ def build_line(args, crd, world, dt, beta, elapsed, kernel, kernel_ms, launches,
     roofline = {"bound": bound, "kernel": kernel, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "frac_wall": achieved_wall / HBM_PEAK_GBS,
                 "achieved_wall": achieved_wall, "traffic": traffic, "traffic_source": traffic_source, "bytes_model": bytes_model, "algorithmic_bytes_per_launch": alg_bytes,
                 "kernel_ms": kernel_ms, "kernel_ms_source": kernel_ms_source, "launches_per_step": launches, "device_ms_per_step": device_ms_per_step, "plan_key": key,
-                "frac_of_device_streaming": hbm_of_streaming if stream_gbs else None}
+                "frac_of_device_streaming": hbm_of_streaming if stream_gbs else None, "kernel_digest": digest,
+                "kernel_table_digest": crd.kernel_table_digest() if hasattr(crd, "kernel_table_digest") else None}
     if issue:
         roofline.update({"issue_frac": issue["issue_frac"], "issue": issue})
         roofline["bound_note"] = ("`bound` = the roof the launch sits closer to: frac_of_device_streaming (compulsory bytes over what this device streams, "
-                                  "profiles/hbm_streams.json) against issue_frac (vector instructions x 4 cycles over the SIMDs' time).  Probe builds of the two-step "
-                                  "kernel (profiles/r05/two_step_memory_path_ab.txt): the launch as a copy takes 0.93 of the full launch's time, its arithmetic alone 0.76")
+                                  "profiles/hbm_streams.json) against issue_frac (vector instructions x 4 cycles over the SIMDs' time).  Probe builds "
+                                  "(profiles/r06/three_step_ab.txt): the two-step launch as a copy takes 0.96 - 1.0 of the full launch's time and its arithmetic alone 0.75; "
+                                  "the three-step launch as a copy 0.73, its arithmetic alone 0.92")
         busy = committed_json("valu_busy.json").get("%s/%s/cols%d/steps%d" % (args.model, args.precision, int(plan.get("columns_per_lane", 1)), per_launch))
         if busy:  # committed SQ counters of the same instantiation, for comparison with issue_frac
             roofline["issue"]["sq_counters"] = busy
     stats = committed_json("plan_stats.json").get(key)
     if stats:  # the committed `rocprofv3 --kernel-trace --stats` record of THIS plan (bench.py --launch-plan pinned)
-        roofline["rocprof_stats"] = stats
+        why = stale_reason(stats, digest, "the --stats record of %s" % key)
+        roofline["rocprof_stats"] = None if why else stats
+        if why:
+            roofline["rocprof_stats_dropped"] = why
     if streams:
         roofline["device_streaming"] = streams
-    if fused and per_launch == 2:
-        roofline["steps_per_launch"] = 2
-        roofline["one_step_per_launch_equivalent"] = {"bytes_per_point_step": 4 * real, "achieved": 2.0 * achieved, "frac": 2.0 * achieved / HBM_PEAK_GBS,
+    if fused and per_launch >= 2:
+        roofline["steps_per_launch"] = per_launch
+        roofline["one_step_per_launch_equivalent"] = {"bytes_per_point_step": 4 * real, "achieved": per_launch * achieved, "frac": per_launch * achieved / HBM_PEAK_GBS,
                                                       "note": "bytes a one-step-per-launch kernel would have to move for the same work, over this launch's time"}
+    if fused and per_launch == 3:
+        # The three-step launch moves 2/3 of the bytes per grid-point-step of the two-step one: its fraction of the HBM roof is LOWER at a
+        # HIGHER rate.  For comparison with earlier rounds' figure (two steps per launch, 16 B per grid-point-step in fp64):
+        roofline["two_steps_per_launch_equivalent"] = {"bytes_per_point_step": 2 * real, "achieved": 1.5 * achieved, "frac": 1.5 * achieved / HBM_PEAK_GBS,
+                                                       "frac_wall": 1.5 * achieved_wall / HBM_PEAK_GBS,
+                                                       "note": "bytes the two-steps-per-launch kernel (rounds 4-5) moves for the same work, over this launch's time"}
     if fused:
         eq = rate(REALS_PER_POINT_STEP * real * pts_launch * per_launch, kernel_ms)
         roofline["survey_8d_equivalent"] = {"bytes_per_point_step": REALS_PER_POINT_STEP * real, "achieved": eq, "frac": eq / HBM_PEAK_GBS,
@@ -519,8 +555,20 @@ def run(args, crd, world, rank, local_rank, device_sync, emit, t_start=None):
         comm["halo_selfcheck"] = {"depth": up["depth"], "fields": 2, "ghost_rows_checked_per_rank": 4 * up["depth"], "mismatching_values": bad_total,
                                   "ok": bad_total == 0 and wrong_count == 0 and wrong_rank == 0}
         if not comm["halo_selfcheck"]["ok"]:
+            if args.preflight and rank == 0:
+                emit(json.dumps({"preflight": True, "ok": False, "n_gpus": world, "halo": comm, "elapsed_s": round(time.monotonic() - t_start, 2),
+                                 "reasons": ["halo self-check: %d ghost values differ; %d ranks see a communicator of the wrong size, %d the wrong rank" % (bad_total, wrong_count, wrong_rank)]}))
             bail("halo self-check failed: %d ghost values differ from the neighbours' rows; %d ranks see a communicator of the wrong size, %d the wrong rank"
                  % (bad_total, wrong_count, wrong_rank))
+    if args.preflight:
+        # PREFLIGHT ends here: every rank answered the roll call, the ring came up, RCCL counts `world` ranks, 32 ghost rows of both fields
+        # arrived from the right neighbours.  Nothing was planned, stepped or timed.
+        if rank == 0:
+            emit(json.dumps({"preflight": True, "ok": True, "n_gpus": world, "halo": comm, "elapsed_s": round(time.monotonic() - t_start, 2),
+                             "kernel_table_digest": crd.kernel_table_digest() if hasattr(crd, "kernel_table_digest") else None}))
+        slab.close()
+        ctl.close()
+        return
     y_init = crd.initial_conditions(cfg, slab.js, slab.je)
     slab.upload(y_init)
 
@@ -608,7 +656,7 @@ def run(args, crd, world, rank, local_rank, device_sync, emit, t_start=None):
     geometry = slab.launch_geometry() if will_fuse and hasattr(slab, "launch_geometry") else None
     # Beside a two-steps-per-launch run (N = 1): the one-step-per-launch kernel, which crosses memory once per step, in this same process.
     one_step = None
-    if world == 1 and will_fuse and plan_used.get("steps_per_launch") == 2 and not args.launch_plan and args.one_step_steps > 0:
+    if world == 1 and will_fuse and plan_used.get("steps_per_launch", 1) >= 2 and not args.launch_plan and args.one_step_steps > 0:
         slab.set_launch_plan(0, plan_used["xcd_mapping"], plan_used["columns_per_lane"], 1, 1)
         slab.step_rk4(0.0, dt, 8, sync=True)
         o_ms, o_kms, _ = slab.step_rk4_timed(0.0, dt, args.one_step_steps)

@@ -30,13 +30,28 @@ def committed_json(name):
         return {}
 
 
-def measured_traffic(kernel_key, points):
+def stale_reason(rec, kernel_digest, what):
+    """Why a committed profile record must not be quoted for the kernel this run launched ("" when it may): records carry the digest of
+    the kernel they were measured on (crdmodel_amd.kernel_digest: registers and loop instruction mix as the assembler printed them)."""
+    if kernel_digest is None or not rec:
+        return ""  # (callers without a kernel to compare with: the tests' stand-in)
+    have = rec.get("kernel_digest", "")
+    if have == kernel_digest:
+        return ""
+    return "%s was measured on another build of this kernel (record %s, loaded library %s): not quoted" % (what, have or "unstamped", kernel_digest or "no kernel table")
+
+
+def measured_traffic(kernel_key, points, kernel_digest=None):
     """(HBM bytes per launch, provenance): the committed result of separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes
     with this plan pinned (profiles/pmc_traffic.json: bytes per grid point), scaled by the points one launch of this run covers --
-    counters need rocprofv3 around the process, the benchmark cannot collect them itself.  (None, reason) when there is no record."""
+    counters need rocprofv3 around the process, the benchmark cannot collect them itself.  (None, reason) when there is no record, or
+    when the record was measured on another build of the kernel (kernel_digest: see stale_reason)."""
     rec = committed_json("pmc_traffic.json").get(kernel_key)
     if not rec:
         return None, "no rocprofv3 --pmc passes recorded for %s" % kernel_key
+    why = stale_reason(rec, kernel_digest, "the --pmc record of %s (%s)" % (kernel_key, rec.get("source", "profiles/pmc_traffic.json")))
+    if why:
+        return None, why
     return rec["bytes_per_point"] * points, "%s: %.2f B/point on %s, rocprofv3 --pmc FETCH_SIZE (x2) + WRITE_SIZE in separate passes; not re-measured by this run" % (
         rec.get("source", "profiles/pmc_traffic.json"), rec["bytes_per_point"], rec.get("grid", "?"))
 
@@ -88,23 +103,20 @@ class ControlPlane:
         if self.dist:
             self.dist.barrier()
 
-    def _reduce(self, values, dtype, op):
+    def _reduce(self, values, dtype_name, op):
+        if not self.dist:  # one process: nothing to reduce, and no torch needed (the stand-in path of the tests)
+            return list(values)
         import torch
 
-        t = torch.tensor(list(values), dtype=dtype)
-        if self.dist:
-            self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
+        t = torch.tensor(list(values), dtype=getattr(torch, dtype_name))
+        self.dist.all_reduce(t, op=getattr(self.dist.ReduceOp, op))
         return t.tolist()
 
     def sum_ints(self, values):
-        import torch
-
-        return [int(v) for v in self._reduce(values, torch.int64, "SUM")]
+        return [int(v) for v in self._reduce(values, "int64", "SUM")]
 
     def max_float(self, value):
-        import torch
-
-        return float(self._reduce([value], torch.float64, "MAX")[0])
+        return float(self._reduce([value], "float64", "MAX")[0])
 
     def broadcast_bytes(self, payload, nbytes, src=0):
         if not self.dist:

@@ -179,7 +179,7 @@ int crd_create_block(const crd_params *p, int c0, int d0, int c1, int d1, int de
 	if (const char *e = std::getenv("CRD_LAUNCH_PLAN")) {
 		int m = -1, k = -1, cols = -1, nt = 0, st = 1;
 		if (std::sscanf(e, "%d,%d,%d,%d,%d", &m, &k, &cols, &nt, &st) >= 3 && m >= 0 && m <= 2 && k >= 0 && k <= 2 && cols >= 1 && cols <= 2 && nt >= 0 && nt <= 1 && st >= 1 &&
-		    st <= 2) {
+		    st <= 3) {
 			c->plan.tuned = c->plan.pinned = 1;
 			c->plan.one_round = m;
 			c->plan.remap = k;
@@ -702,8 +702,8 @@ int crd_set_launch_plan(crd_ctx *c, int chunk_mode, int xcd_mapping, int columns
 {
 	if (!c) return CRD_EINVAL;
 	if (chunk_mode < 0 || chunk_mode > 2 || xcd_mapping < 0 || xcd_mapping > 2 || columns_per_lane < 1 || columns_per_lane > 2 || nontemporal_stores < 0 ||
-	    nontemporal_stores > 1 || steps_per_launch < 1 || steps_per_launch > 2)
-		return fail(c, CRD_EINVAL, "crd_set_launch_plan: chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1, steps per launch 1..2");
+	    nontemporal_stores > 1 || steps_per_launch < 1 || steps_per_launch > 3)
+		return fail(c, CRD_EINVAL, "crd_set_launch_plan: chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1, steps per launch 1..3");
 	// (the error-controlled integrators' instantiations take the plan too; they step one column per lane whatever it says)
 	for (FusedPlan *pl : {&c->plan, &c->plan_embed, &c->plan_arkode}) {
 		pl->tuned = pl->pinned = 1;
@@ -729,7 +729,7 @@ int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
 	// (without a plan the launches take the default of their precision: two columns per lane in fp32 on an even nx)
 	out->columns_per_lane = c->plan.tuned ? c->plan.cols : fused_default_columns(c->p.precision, c->nx);
 	out->nontemporal_stores = c->plan.nt;
-	out->steps_per_launch = (c->plan.tuned && c->plan.steps == 2 && fused_two_steps_supported(c->desc)) ? 2 : 1;
+	out->steps_per_launch = c->plan.tuned ? fused_steps_supported(c->p.precision, c->desc, c->plan.steps) : 1;
 	out->ms_default = c->plan.ms_default;
 	out->ms_chosen = c->plan.ms_best;
 	return CRD_OK;
@@ -747,7 +747,13 @@ int crd_get_launch_geometry(crd_ctx *c, crd_launch_geometry *out)
 	FusedGeometry g{};
 	FusedCall call{};
 	call.dt = 1.0;
-	call.steps = (c->plan.tuned && c->plan.steps == 2 && fused_two_steps_supported(c->desc)) ? 2 : 1;
+	// the stage flags of the last step the context took (none taken: of a step at t = 0): which instantiation a launch there runs
+	{
+		const double cs4[4] = {0.0, 0.5, 0.5, 1.0}, dt_last = c->last_step_dt > 0.0 ? c->last_step_dt : 0.0;
+		for (int k = 0; k < 4; k++) call.absorb[k] = absorbing(c, c->last_step_t + cs4[k] * dt_last) ? 1 : 0;
+		call.absorb[4] = call.absorb[3];
+	}
+	call.steps = c->plan.tuned ? fused_steps_supported(c->p.precision, c->desc, c->plan.steps) : 1;
 	call.plan = &c->plan;
 	call.geometry = &g;
 	HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));

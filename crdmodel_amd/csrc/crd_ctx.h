@@ -170,6 +170,9 @@ struct crd_ctx {
 	double deferred_t = 0.0;      // that launch's time
 	int deferred_nsub = 1;        // ... and how many steps it takes (1, or 2 under a two-steps-per-launch plan)
 	int cycle_pos = -1;
+	// time and step of the last fixed step a stepping call issued: crd_get_launch_geometry reports the kernel a step THERE runs (with the
+	// absorbing rows on, t < tBoundary, a one-step launch runs the instantiation with the selects)
+	double last_step_t = 0.0, last_step_dt = 0.0;
 	int xchg_plane = 0;    // the state plane the exchange in progress sends this context's rows from (LOCAL neighbours pull from it)
 	int timed_rows = 0;    // rows of the multi-slab fused launch crd_step_rk4_timed last put its events around
 	int timed_steps = 0;   // steps per launch of the launches the last timed call put its events around (all alike: 1, or 2)

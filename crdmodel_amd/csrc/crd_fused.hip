@@ -8,6 +8,15 @@ bool fused_step_supported(int, const SlabDesc &d) { return d.nyl >= 2 * kStepHal
 
 bool fused_two_steps_supported(const SlabDesc &d) { return d.nyl >= 4 * kStepHalo && kernel_model(d) != kModelDiffusionOnly; }
 
+// Steps one launch of this slab takes when the plan asks for `want` (1 .. 3): three only where the three-step kernel exists (FHN, fp64:
+// kCanThreeSteps) and on a single slab (rows wrap; the exchange cycles of multi-slab runs step pairs), else two where the two-step
+// kernels do, else one.
+int fused_steps_supported(int precision, const SlabDesc &d, int want)
+{
+	if (want >= 3 && precision == CRD_PRECISION_F64 && kernel_model(d) == CRD_MODEL_FHN && d.wrap && d.nyl >= 6 * kStepHalo) return 3;
+	return (want >= 2 && fused_two_steps_supported(d)) ? 2 : 1;
+}
+
 int fused_max_items(const SlabDesc &d)
 {
 	// upper bound on the work items of any launch on this slab: the narrowest strips, the shortest chunks the heuristic uses

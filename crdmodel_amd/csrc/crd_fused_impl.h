@@ -131,20 +131,32 @@ __device__ __forceinline__ void rhs_lane(V uC, V uS, V uN, V v, V cE, V cWn, V c
 // one (280).  So: Goldbeter, bound by issue, runs 6 - 8 % faster (4096^2: 0.111 -> 0.102 ms per step); FHN, bound by its memory
 // traffic, does not (8192^2 0.2200 -> 0.2195; 4096^2 2 % slower) and keeps a strip per wavefront.
 // profiles/r05/block_strip_ab.txt; round 4 tried the same at 173 VGPRs -- two wavefronts per SIMD -- and lost 13 %.
-#if defined(CRD_COOP_ALL)  // (experiment switches: every fp64 one-column two-step pipeline / none)
-template <typename Real, int MODEL, int COLS>
+// THREE steps per launch (round 6) run the block as the strip in FHN too: with a strip per wavefront the apron would be 12 columns a
+// side, 40 valid lanes of 64; around a block it is 232 of 256.
+#if defined(CRD_COOP_ALL)  // (experiment switches: every fp64 one-column multi-step pipeline / none)
+template <typename Real, int MODEL, int COLS, int STEPS = 2>
 constexpr bool kCoop = sizeof(Real) == 8 && COLS == 1;
 #elif defined(CRD_NO_COOP)
-template <typename Real, int MODEL, int COLS>
+template <typename Real, int MODEL, int COLS, int STEPS = 2>
 constexpr bool kCoop = false;
 #else
-template <typename Real, int MODEL, int COLS>
-constexpr bool kCoop = sizeof(Real) == 8 && COLS == 1 && MODEL == CRD_MODEL_GOLDBETER;
+template <typename Real, int MODEL, int COLS, int STEPS = 2>
+constexpr bool kCoop = sizeof(Real) == 8 && COLS == 1 && (MODEL == CRD_MODEL_GOLDBETER || STEPS == 3);
 #endif
-constexpr int kEdgeSlotBytes = 64;                                                // eight doubles: the eight quantities of an iteration
-constexpr int kEdgeParityBytes = 4 /* kMaxWavesPerBlock */ * 2 * kEdgeSlotBytes;  // [wavefront][side]
-constexpr int kEdgeBytes = 2 * kEdgeParityBytes;                                  // [parity]
-constexpr int kEdgeDumpBytes = 4 /* kMaxWavesPerBlock */ * 64 * 8 + kEdgeBytes;   // where the lanes in between drop their values (+ the largest slot offset)
+// An edge slot holds the 4 STEPS quantities of an iteration (each step's input row and its three stage values): 64 B at two steps,
+// 96 of 128 at three.
+// (Round 6 tried slots placed on the LDS banks lanes 0 / 63 would have had in the dump area -- lane 63's slot shares its banks with lane
+// 48's dump address, SQ_LDS_BANK_CONFLICT 13.5 % of the LDS cycles; the eastern slot is then 8- but not 16-byte aligned and the readers
+// need ds_read2_b64, eight LDS cycles each instead of four: the three-step launch 3.8 % SLOWER (0.2040 -> 0.2118 ms per step).  A store's
+// cost is the transfer of its operands to the LDS, six cycles whatever the banks do; profiles/r06/three_step_ab.txt.)
+template <int STEPS>
+constexpr int kEdgeSlotBytes = STEPS == 3 ? 128 : 64;
+template <int STEPS>
+constexpr int kEdgeParityBytes = 4 /* kMaxWavesPerBlock */ * 2 * kEdgeSlotBytes<STEPS>;  // [wavefront][side]
+template <int STEPS>
+constexpr int kEdgeBytes = 2 * kEdgeParityBytes<STEPS>;                                  // [parity]
+template <int STEPS>
+constexpr int kEdgeDumpBytes = 4 /* kMaxWavesPerBlock */ * 64 * 8 + kEdgeBytes<STEPS>;   // where the lanes in between drop their values (+ the largest slot offset)
 __device__ __forceinline__ double from_lane_below_old(double x, double old)
 {
 	int lo = __double2loint(x), hi = __double2hiint(x);
@@ -171,18 +183,36 @@ __device__ __forceinline__ void rhs_lane_edge(double uC, double X, double uS, do
 template <int OFF>
 __device__ __forceinline__ void edge_publish(unsigned pub, double val)
 {
+#ifndef CRD_PROBE_NOPUBLISH  // (probe build: what the publishes cost -- results are wrong without them)
 	asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(pub), "v"(val), "n"(OFF) : "memory");
+#endif
 }
 typedef double double2r __attribute__((ext_vector_type(2)));
+#ifdef CRD_PROBE_NOBARRIER  // (probe build: what the iteration's barrier costs -- results are wrong without it)
+#define CRD_EDGE_BARRIER "s_nop 0"
+#else
+#define CRD_EDGE_BARRIER "s_barrier"
+#endif
 constexpr unsigned long kEdgeLanes = 0x8000000000000001ul;  // exec mask: lanes 0 and 63
 // The barrier of an iteration (this wavefront's own publishes have landed: lgkmcnt(0)), and behind it the reads -- issued, not waited
-// for: ring_read_with_edges does that -- of the eight quantities the neighbours published during it: 64 B from OFF on, into lanes 0 and 63.
+// for: ring_read_with_edges does that -- of the 4 STEPS quantities the neighbours published during it: 16 N bytes from OFF on, into
+// lanes 0 and 63.
 template <int OFF>
-__device__ __forceinline__ void edge_exchange(unsigned con, double2r &e01, double2r &e23, double2r &e45, double2r &e67)
+__device__ __forceinline__ void edge_exchange(unsigned con, double2r (&e)[4])
 {
-	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier\n\ts_mov_b64 exec, %5\n\tds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\t"
+	asm volatile("s_waitcnt lgkmcnt(0)\n\t" CRD_EDGE_BARRIER "\n\ts_mov_b64 exec, %5\n\tds_read_b128 %0, %4 offset:%6\n\tds_read_b128 %1, %4 offset:%7\n\t"
 	             "ds_read_b128 %2, %4 offset:%8\n\tds_read_b128 %3, %4 offset:%9\n\ts_mov_b64 exec, -1"
-	             : "=&v"(e01), "=&v"(e23), "=&v"(e45), "=&v"(e67) : "v"(con), "s"(kEdgeLanes), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48) : "memory");
+	             : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]) : "v"(con), "s"(kEdgeLanes), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48) : "memory");
+}
+template <int OFF>
+__device__ __forceinline__ void edge_exchange(unsigned con, double2r (&e)[6])
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\t" CRD_EDGE_BARRIER "\n\ts_mov_b64 exec, %7\n\tds_read_b128 %0, %6 offset:%8\n\tds_read_b128 %1, %6 offset:%9\n\t"
+	             "ds_read_b128 %2, %6 offset:%10\n\tds_read_b128 %3, %6 offset:%11\n\tds_read_b128 %4, %6 offset:%12\n\tds_read_b128 %5, %6 offset:%13\n\t"
+	             "s_mov_b64 exec, -1"
+	             : "=&v"(e[0]), "=&v"(e[1]), "=&v"(e[2]), "=&v"(e[3]), "=&v"(e[4]), "=&v"(e[5])
+	             : "v"(con), "s"(kEdgeLanes), "n"(OFF), "n"(OFF + 16), "n"(OFF + 32), "n"(OFF + 48), "n"(OFF + 64), "n"(OFF + 80)
+	             : "memory");
 }
 
 // f(integral_constant<int, 0>{}), f(integral_constant<int, 1>{}), ... in order: a compile-time unrolled loop.
@@ -247,6 +277,7 @@ struct FusedArgs {
 	Real h2, h3, h6, h1;      // dt/2, dt/3, dt/6, dt
 	int absorb[5];            // t_stage < tBoundary for the four stages (+ the embedded pair's fifth)
 	int absorb2[4];           // two steps per launch: the second step's stages
+	int absorb3[4];           // three: the third's
 	int js, ny;               // global index of local row 0, global row count (absorbing rule is by global row)
 	// Rows this launch produces: one or two ranges, cut into work items ("chunks") of `chunk` rows; chunk ids run through the
 	// ranges in order (range 1 starts at id `first2`).  One range: an ordinary sweep.  Two: the rows of a step that read ghost
@@ -569,8 +600,12 @@ __device__ __forceinline__ V stage_fma(V h, V k, V y)
 #endif
 constexpr int kRingRowsWanted = CRD_RING_ROWS;  // a multiple of the unroll factor 4; rows in flight per wavefront
 // ... as far as the six bits of vmcnt allow (a row of 1 KiB per field takes eight LDS-DMA instructions)
-template <typename V>
-constexpr int kRingRowsOf = (kLanes * (int)sizeof(V) / 256 >= 4 && kRingRowsWanted > 4) ? 4 : kRingRowsWanted;
+#ifndef CRD_RING_ROWS_THREE
+#define CRD_RING_ROWS_THREE 8
+#endif
+// (three steps per launch: two wavefronts per SIMD -- eight rows in flight per wavefront for the bytes in flight twelve wavefronts of four had)
+template <typename V, int STEPS = 2>
+constexpr int kRingRowsOf = (kLanes * (int)sizeof(V) / 256 >= 4 && (STEPS == 3 ? CRD_RING_ROWS_THREE : kRingRowsWanted) > 4) ? 4 : (STEPS == 3 ? CRD_RING_ROWS_THREE : kRingRowsWanted);
 typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) char lds_char;
@@ -607,16 +642,22 @@ __device__ __forceinline__ void ring_read(unsigned lds_lane, V &u, V &v)
 }
 // ... and the wait covers the edge reads in flight too (edge_exchange): they pass through as operands, so that nothing uses them before it
 template <int VMCNT, int OFF_U, int OFF_V>
-__device__ __forceinline__ void ring_read_with_edges(unsigned lds_lane, double &u, double &v, double2r &e01, double2r &e23, double2r &e45, double2r &e67)
+__device__ __forceinline__ void ring_read_with_edges(unsigned lds_lane, double &u, double &v, double2r (&e)[4])
 {
 	asm volatile("s_waitcnt vmcnt(%7)\n\tds_read_b64 %0, %6 offset:%8\n\tds_read_b64 %1, %6 offset:%9\n\ts_waitcnt lgkmcnt(0)"
-	             : "=&v"(u), "=&v"(v), "+v"(e01), "+v"(e23), "+v"(e45), "+v"(e67) : "v"(lds_lane), "n"(VMCNT), "n"(OFF_U), "n"(OFF_V) : "memory");
+	             : "=&v"(u), "=&v"(v), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]) : "v"(lds_lane), "n"(VMCNT), "n"(OFF_U), "n"(OFF_V) : "memory");
 }
-template <int VMCNT, int OFF_U, int OFF_V, typename V>
-__device__ __forceinline__ void ring_read_with_edges(unsigned, V &, V &, double2r &, double2r &, double2r &, double2r &) {}  // (COOP is fp64, one column per lane)
+template <int VMCNT, int OFF_U, int OFF_V>
+__device__ __forceinline__ void ring_read_with_edges(unsigned lds_lane, double &u, double &v, double2r (&e)[6])
+{
+	asm volatile("s_waitcnt vmcnt(%9)\n\tds_read_b64 %0, %8 offset:%10\n\tds_read_b64 %1, %8 offset:%11\n\ts_waitcnt lgkmcnt(0)"
+	             : "=&v"(u), "=&v"(v), "+v"(e[0]), "+v"(e[1]), "+v"(e[2]), "+v"(e[3]), "+v"(e[4]), "+v"(e[5]) : "v"(lds_lane), "n"(VMCNT), "n"(OFF_U), "n"(OFF_V) : "memory");
+}
+template <int VMCNT, int OFF_U, int OFF_V, typename V, int N>
+__device__ __forceinline__ void ring_read_with_edges(unsigned, V &, V &, double2r (&)[N]) {}  // (COOP is fp64, one column per lane)
 // LDS bytes of a block's rings
-template <typename Real, int COLS>
-constexpr int kRingBytes = kMaxWavesPerBlock * kRingRowsOf<typename LaneValue<Real, COLS>::type> * 2 * kLanes * COLS * (int)sizeof(Real);
+template <typename Real, int COLS, int STEPS = 2>
+constexpr int kRingBytes = kMaxWavesPerBlock * kRingRowsOf<typename LaneValue<Real, COLS>::type, STEPS> * 2 * kLanes * COLS * (int)sizeof(Real);
 
 // TWO classical RK4 steps of the item's rows in one pass over memory (STEPS = 2): the pipeline of fused_item twice over, eight stages
 // deep -- iteration m takes row p (out of its LDS ring slot), runs stages 1..4 of step n on rows p-1 .. p-4, hands the new row p-4
@@ -630,23 +671,29 @@ constexpr int kRingBytes = kMaxWavesPerBlock * kRingRowsOf<typename LaneValue<Re
 // Slot arithmetic: row r of either pipeline lives in slot r mod 4; the second pipeline's rows are the first one's shifted by 4,
 // i.e. the SAME slots -- the stage code is one lambda applied to two sets of arrays.  Per point the arithmetic is the sequence of
 // two single steps exactly (same fused multiply-adds, same constants), so the result is theirs bit for bit.
-template <typename Real, int MODEL, bool ABSORB, int COLS, bool NT>
-__device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk, lds_char *const block_rings,
-                                                     const int sblk = 0, lds_char *const block_edges = nullptr)
+template <typename Real, int MODEL, bool ABSORB, int COLS, bool NT, int STEPS = 2>
+__device__ __forceinline__ void fused_item_multi_step(const Slab<Real> &s, const FusedArgs<Real> &a, const int strip, const int chunk, lds_char *const block_rings,
+                                                      const int sblk = 0, lds_char *const block_edges = nullptr)
 {
-	constexpr bool COOP = kCoop<Real, MODEL, COLS>;
+	static_assert(STEPS == 2 || STEPS == 3, "two or three steps per launch");
+	constexpr bool COOP = kCoop<Real, MODEL, COLS, STEPS>;
 #ifdef CRD_NO_SETPRIO
 	constexpr bool PRIO = false;
 #else
+#ifdef CRD_PRIO_THREE  // (experiment switch: the three-step pipeline's memory operations at raised priority too)
 	constexpr bool PRIO = sizeof(Real) == 8 && COLS == 1 && MODEL == CRD_MODEL_FHN;
+#else
+	constexpr bool PRIO = sizeof(Real) == 8 && COLS == 1 && MODEL == CRD_MODEL_FHN && STEPS == 2;
+#endif
 #endif
 	using V = typename LaneValue<Real, COLS>::type;
-	constexpr int APRON = 2 * kApron;
+	constexpr int APRON = STEPS * kApron;
+	constexpr int FILL = 2 * APRON;  // iterations of a chunk before rows come out: stage k of step n has inputs from iteration 8 n + 2 k on
 	static_assert(APRON % COLS == 0, "the apron is whole lanes");
 	constexpr int VALID = COLS * kLanes - 2 * APRON;
 	constexpr int M = 4;
 	// the ring: kRingRows slots of [u row segment | v row segment], RB bytes each, filled 256 B (64 lanes x one dword) per LDS-DMA
-	constexpr int RB = kLanes * (int)sizeof(V), SLOT = 2 * RB, G1 = RB / 256, kRingRows = kRingRowsOf<V>;
+	constexpr int RB = kLanes * (int)sizeof(V), SLOT = 2 * RB, G1 = RB / 256, kRingRows = kRingRowsOf<V, STEPS>;
 	static_assert(kRingRows % M == 0 && kRingRows >= M && (kRingRows & (kRingRows - 1)) == 0, "ring slots are addressed with the unrolled iteration index");
 	// vector-memory operations a wavefront issues per iteration: 2 G1 LDS-DMA loads, and 2 stores once rows come out.  When the slot
 	// of iteration m is read, the operations issued after its fill (at iteration m - kRingRows) are the fills of kRingRows - 1
@@ -689,7 +736,7 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	};
 	// Global phi boundary rows (src/FHNmodel_torus.cpp:643-653).  Rows ny - 1 and 0 are neighbours on the periodic grid: within the rows
 	// this item's pipeline touches (fewer than 2 ny of them) they are local rows jb, jb + 1 and possibly jb + ny, jb + ny + 1.  Two
-	// scalars and a bit mask of the eight stage flags instead of js, ny and eight flag words: the body with the selects must not need
+	// scalars and a bit mask of the 4 STEPS stage flags instead of js, ny and as many flag words: the body with the selects must not need
 	// more registers than the one without (168 VGPRs = three wavefronts per SIMD), or the launch's kernel, which holds both, runs
 	// every item at two.
 	int jb = 0, amask = 0;
@@ -698,7 +745,7 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		if (g0 < 0) g0 += a.ny;
 		jb = jbase + (a.ny - 1 - g0);
 #pragma unroll
-		for (int k = 0; k < 4; k++) amask |= (a.absorb[k] ? 1 << k : 0) | (a.absorb2[k] ? 16 << k : 0);
+		for (int k = 0; k < 4; k++) amask |= (a.absorb[k] ? 1 << k : 0) | (a.absorb2[k] ? 16 << k : 0) | ((STEPS == 3 && a.absorb3[k]) ? 256 << k : 0);
 		jb = __builtin_amdgcn_readfirstlane(jb);
 		amask = __builtin_amdgcn_readfirstlane(amask);
 	}
@@ -709,16 +756,17 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		V u0[M], v0[M], U1[M], U2[M], U3[M], V1[2], V2[2], V3[2], aU[M], aV[M];
 		Real bq[M];
 	};
-	Pipe A, B;
+	Pipe P[STEPS];  // P[n]: the pipeline of step n of the launch; its input rows are P[n - 1]'s output rows
 	const V zero_v = splat<V>(0.0);
 #pragma unroll
-	for (int k = 0; k < M; k++) {
-		A.u0[k] = A.v0[k] = A.U1[k] = A.U2[k] = A.U3[k] = A.aU[k] = A.aV[k] = zero_v;
-		B.u0[k] = B.v0[k] = B.U1[k] = B.U2[k] = B.U3[k] = B.aU[k] = B.aV[k] = zero_v;
-		A.bq[k] = B.bq[k] = (Real)0;
+	for (int n = 0; n < STEPS; n++) {
+#pragma unroll
+		for (int k = 0; k < M; k++) {
+			P[n].u0[k] = P[n].v0[k] = P[n].U1[k] = P[n].U2[k] = P[n].U3[k] = P[n].aU[k] = P[n].aV[k] = zero_v;
+			P[n].bq[k] = (Real)0;
+		}
+		P[n].V1[0] = P[n].V1[1] = P[n].V2[0] = P[n].V2[1] = P[n].V3[0] = P[n].V3[1] = zero_v;
 	}
-	A.V1[0] = A.V1[1] = A.V2[0] = A.V2[1] = A.V3[0] = A.V3[1] = zero_v;
-	B.V1[0] = B.V1[1] = B.V2[0] = B.V2[1] = B.V3[0] = B.V3[1] = zero_v;
 
 	// This wavefront's ring, and where its lanes read: lane l takes the l-th value (of sizeof(V) bytes) of a row segment.
 	lds_char *const ring = block_rings + wave * (kRingRows * SLOT);
@@ -728,9 +776,9 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	unsigned edge_pub = 0, edge_con = 0;
 	if constexpr (COOP) {
 		const unsigned base = (unsigned)(uintptr_t)block_edges;
-		edge_pub = (lane == 0 || lane == kLanes - 1) ? base + (unsigned)((wave * 2 + (lane == 0 ? 0 : 1)) * kEdgeSlotBytes)
-		                                             : base + (unsigned)(kEdgeBytes + (wave * kLanes + lane) * 8);
-		edge_con = base + (unsigned)((lane == 0 ? (wave > 0 ? wave - 1 : wave) * 2 + 1 : (wave + 1 < a.sw ? wave + 1 : wave) * 2) * kEdgeSlotBytes);
+		edge_pub = (lane == 0 || lane == kLanes - 1) ? base + (unsigned)((wave * 2 + (lane == 0 ? 0 : 1)) * kEdgeSlotBytes<STEPS>)
+		                                             : base + (unsigned)(kEdgeBytes<STEPS> + (wave * kLanes + lane) * 8);
+		edge_con = base + (unsigned)((lane == 0 ? (wave > 0 ? wave - 1 : wave) * 2 + 1 : (wave + 1 < a.sw ? wave + 1 : wave) * 2) * kEdgeSlotBytes<STEPS>);
 	}
 	const unsigned ring_lane = (unsigned)(uintptr_t)ring + (unsigned)lane * (unsigned)sizeof(V);
 	// ... and what they fetch: LDS-DMA instruction h of a row moves dwords 64 h + lane of the segment; the column of a dword's
@@ -757,58 +805,61 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 	Real pb = brow[jbase];                                            // b(j) of the row the next iteration takes
 	int trip_byte = 0;                                                // ring byte offset of the slots of this trip of four iterations
 	unsigned ring_trip = ring_lane;
-	Real *out_row_u = a.out_u + (ptrdiff_t)(jbase - 2 * kApron) * nx, *out_row_v = a.out_v + (ptrdiff_t)(jbase - 2 * kApron) * nx;
+	// (the rows that come out of the last pipeline at iteration m: row jbase + m - 4 STEPS)
+	Real *out_row_u = a.out_u + (ptrdiff_t)(jbase - APRON) * nx, *out_row_v = a.out_v + (ptrdiff_t)(jbase - APRON) * nx;
 
 	// Stages 1..4 of one step on the pipeline P whose newest row is `p` (slot S0): new state of row p - 4 in (nu, nv).
 	// flag_bit: where the step's four stage flags start in amask; b4: b(j) of row p - 4 (read by the caller before row p took over its slot).
-	// `live`: the iterations this pipeline has been fed for (m for the first, m - 8 for the second; 8 and more: all stages run).  In the
-	// chunk's first sixteen iterations stage k has complete inputs only from the pipeline's iteration 2 k on -- the stages before that are
+	// `live`: the iterations this pipeline has been fed for (m for the first, m - 8 n for the n-th; 8 and more: all stages run).  In the
+	// chunk's first 8 STEPS iterations stage k has complete inputs only from the pipeline's iteration 2 k on -- the stages before that are
 	// skipped (their rows lie outside what the chunk's outputs depend on: nothing downstream reads what they would have written).  Half
 	// the work of those iterations, which is a tenth of a 61-row item's -- one rank's share of an 8-GPU run -- and a third of an edge band's.
-	[[maybe_unused]] double2r e01 = {0.0, 0.0}, e23 = {0.0, 0.0}, e45 = {0.0, 0.0}, e67 = {0.0, 0.0};  // (COOP) the neighbours' edge values, lanes 0 and 63
+	[[maybe_unused]] double2r edge[2 * STEPS];  // (COOP) the neighbours' edge values, lanes 0 and 63: quantity q of an iteration in edge[q / 2]
+#pragma unroll
+	for (int q = 0; q < 2 * STEPS; q++) edge[q] = double2r{0.0, 0.0};
 	auto point = [&](V uC, V uS, V uN, V v, Real rowp, bool zero, [[maybe_unused]] V X, V &du, V &dv) {
 		if constexpr (COOP) rhs_lane_edge<MODEL>(uC, X, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
 		else rhs_lane<V, MODEL>(uC, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
 	};
-	auto stages = [&](Pipe &P, const int p, auto kk, auto live_c, const int flag_bit, const Real b4, V &nu, V &nv, [[maybe_unused]] const V (&E)[4], auto qbase_c) {
+	auto stages = [&](Pipe &Q, const int p, auto kk, auto live_c, const int flag_bit, const Real b4, V &nu, V &nv, [[maybe_unused]] const V (&E)[4], auto qbase_c) {
 		constexpr int K = decltype(kk)::value;
-		[[maybe_unused]] constexpr int PUB = (K & 1) * kEdgeParityBytes + decltype(qbase_c)::value * 8;
-		constexpr int live = decltype(live_c)::value;  // (compile-time: the sixteen filling iterations are sixteen pieces of straight-line code)
+		[[maybe_unused]] constexpr int PUB = (K & 1) * kEdgeParityBytes<STEPS> + decltype(qbase_c)::value * 8;
+		constexpr int live = decltype(live_c)::value;  // (compile-time: the filling iterations are so many pieces of straight-line code)
 		constexpr int S0 = K % M, S1 = (K + M - 1) % M, S2 = (K + M - 2) % M, S3 = (K + M - 3) % M, S4 = (K + 2 * M - 4) % M, S5 = (K + 2 * M - 5) % M;
 		V du, dv;
 		if constexpr (live >= 2) {
-			point(P.u0[S1], P.u0[S2], P.u0[S0], P.v0[S1], P.bq[S1], ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), E[0], du, dv);
-			P.U1[S1] = stage_fma(h2, du, P.u0[S1]);
-			if constexpr (COOP) edge_publish<PUB + 8>(edge_pub, P.U1[S1]);
-			P.V1[S1 & 1] = stage_fma(h2, dv, P.v0[S1]);
-			P.aU[S1] = stage_fma(h6, du, P.u0[S1]);
-			P.aV[S1] = stage_fma(h6, dv, P.v0[S1]);
+			point(Q.u0[S1], Q.u0[S2], Q.u0[S0], Q.v0[S1], Q.bq[S1], ABSORB && ((amask >> (flag_bit + 0)) & 1) && boundary_row(p - 1), E[0], du, dv);
+			Q.U1[S1] = stage_fma(h2, du, Q.u0[S1]);
+			if constexpr (COOP) edge_publish<PUB + 8>(edge_pub, Q.U1[S1]);
+			Q.V1[S1 & 1] = stage_fma(h2, dv, Q.v0[S1]);
+			Q.aU[S1] = stage_fma(h6, du, Q.u0[S1]);
+			Q.aV[S1] = stage_fma(h6, dv, Q.v0[S1]);
 		}
 		if constexpr (live >= 4) {
-			point(P.U1[S2], P.U1[S3], P.U1[S1], P.V1[S2 & 1], P.bq[S2], ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), E[1], du, dv);
-			P.U2[S2] = stage_fma(h2, du, P.u0[S2]);
-			if constexpr (COOP) edge_publish<PUB + 16>(edge_pub, P.U2[S2]);
-			P.V2[S2 & 1] = stage_fma(h2, dv, P.v0[S2]);
-			P.aU[S2] = stage_fma(h3, du, P.aU[S2]);
-			P.aV[S2] = stage_fma(h3, dv, P.aV[S2]);
+			point(Q.U1[S2], Q.U1[S3], Q.U1[S1], Q.V1[S2 & 1], Q.bq[S2], ABSORB && ((amask >> (flag_bit + 1)) & 1) && boundary_row(p - 2), E[1], du, dv);
+			Q.U2[S2] = stage_fma(h2, du, Q.u0[S2]);
+			if constexpr (COOP) edge_publish<PUB + 16>(edge_pub, Q.U2[S2]);
+			Q.V2[S2 & 1] = stage_fma(h2, dv, Q.v0[S2]);
+			Q.aU[S2] = stage_fma(h3, du, Q.aU[S2]);
+			Q.aV[S2] = stage_fma(h3, dv, Q.aV[S2]);
 		}
 		if constexpr (live >= 6) {
-			point(P.U2[S3], P.U2[S4], P.U2[S2], P.V2[S3 & 1], P.bq[S3], ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), E[2], du, dv);
-			P.U3[S3] = stage_fma(h1, du, P.u0[S3]);
-			if constexpr (COOP) edge_publish<PUB + 24>(edge_pub, P.U3[S3]);
-			P.V3[S3 & 1] = stage_fma(h1, dv, P.v0[S3]);
-			P.aU[S3] = stage_fma(h3, du, P.aU[S3]);
-			P.aV[S3] = stage_fma(h3, dv, P.aV[S3]);
+			point(Q.U2[S3], Q.U2[S4], Q.U2[S2], Q.V2[S3 & 1], Q.bq[S3], ABSORB && ((amask >> (flag_bit + 2)) & 1) && boundary_row(p - 3), E[2], du, dv);
+			Q.U3[S3] = stage_fma(h1, du, Q.u0[S3]);
+			if constexpr (COOP) edge_publish<PUB + 24>(edge_pub, Q.U3[S3]);
+			Q.V3[S3 & 1] = stage_fma(h1, dv, Q.v0[S3]);
+			Q.aU[S3] = stage_fma(h3, du, Q.aU[S3]);
+			Q.aV[S3] = stage_fma(h3, dv, Q.aV[S3]);
 		}
 		nu = nv = zero_v;
 		if constexpr (live >= 8) {
-			point(P.U3[S4], P.U3[S5], P.U3[S3], P.V3[S4 & 1], b4, ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), E[3], du, dv);
-			nu = stage_fma(h6, du, P.aU[S4]);
-			nv = stage_fma(h6, dv, P.aV[S4]);
+			point(Q.U3[S4], Q.U3[S5], Q.U3[S3], Q.V3[S4 & 1], b4, ABSORB && ((amask >> (flag_bit + 3)) & 1) && boundary_row(p - 4), E[3], du, dv);
+			nu = stage_fma(h6, du, Q.aU[S4]);
+			nv = stage_fma(h6, dv, Q.aV[S4]);
 		}
 	};
 	auto iteration = [&](int m, auto kk, auto fed_c) {
-		constexpr int FED = decltype(fed_c)::value;  // iterations before this one, if fewer than sixteen
+		constexpr int FED = decltype(fed_c)::value;  // iterations before this one, if fewer than FILL
 		constexpr int K = decltype(kk)::value;
 		constexpr int S0 = K % M, S4 = (K + 2 * M - 4) % M;
 #if !defined(CRD_NO_LOCKSTEP) && !defined(CRD_NO_LOCKSTEP_TWO)
@@ -818,21 +869,25 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		if constexpr (sizeof(Real) == 4) __builtin_amdgcn_s_barrier();
 #endif
 		const int p = jbase + m;
-		const Real b4a = A.bq[S4], b4b = B.bq[S4];
+		Real b4[STEPS];  // b(j) of the rows stage 4 of each step works on, read before row p takes over the slot
+#pragma unroll
+		for (int n = 0; n < STEPS; n++) b4[n] = P[n].bq[S4];
 		// row p out of its ring slot (filled kRingRows iterations ago) ...
-		if (m < 4 * kApron + kRingRows) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitFill) : "memory");  // (fewer operations in flight while no rows come out yet)
-		V EA[4], EB[4];
+		if (m < FILL + kRingRows) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kWaitFill) : "memory");  // (fewer operations in flight while no rows come out yet)
+		V E[STEPS][4];
 		if constexpr (COOP) {
 			// ... together with the neighbours' edge values, whose reads the previous iteration issued behind its barrier
-			ring_read_with_edges<kWaitSteady, S0 * SLOT, S0 * SLOT + RB>(ring_trip, A.u0[S0], A.v0[S0], e01, e23, e45, e67);
-			EA[0] = e01.x, EA[1] = e01.y, EA[2] = e23.x, EA[3] = e23.y, EB[0] = e45.x, EB[1] = e45.y, EB[2] = e67.x, EB[3] = e67.y;
-			edge_publish<(K & 1) * kEdgeParityBytes>(edge_pub, A.u0[S0]);
+			ring_read_with_edges<kWaitSteady, S0 * SLOT, S0 * SLOT + RB>(ring_trip, P[0].u0[S0], P[0].v0[S0], edge);
+#pragma unroll
+			for (int n = 0; n < STEPS; n++) E[n][0] = edge[2 * n].x, E[n][1] = edge[2 * n].y, E[n][2] = edge[2 * n + 1].x, E[n][3] = edge[2 * n + 1].y;
+			edge_publish<(K & 1) * kEdgeParityBytes<STEPS>>(edge_pub, P[0].u0[S0]);
 		} else {
-			ring_read<kWaitSteady, S0 * SLOT, S0 * SLOT + RB>(ring_trip, A.u0[S0], A.v0[S0]);
-			EA[0] = EA[1] = EA[2] = EA[3] = EB[0] = EB[1] = EB[2] = EB[3] = zero_v;
+			ring_read<kWaitSteady, S0 * SLOT, S0 * SLOT + RB>(ring_trip, P[0].u0[S0], P[0].v0[S0]);
+#pragma unroll
+			for (int n = 0; n < STEPS; n++) E[n][0] = E[n][1] = E[n][2] = E[n][3] = zero_v;
 		}
-		A.bq[S0] = uniform(pb);
-#ifndef CRD_PROBE_NOLOAD  // (probe builds, tools/build_variant.sh: what a launch costs without its row reads / its second step / its stores)
+		P[0].bq[S0] = uniform(pb);
+#ifndef CRD_PROBE_NOLOAD  // (probe builds, tools/build_variant.sh: what a launch costs without its row reads / its later steps / its stores)
 		fill(jn, trip_byte + S0 * SLOT);  // ... and row p + kRingRows into it
 #endif
 		jn = (jn < jlast) ? jn + 1 : jlast;
@@ -840,17 +895,26 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		V nu, nv;
 		if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);  // (see the stores below)
 #ifdef CRD_PROBE_NOMATH  // (probe build: the launch as a copy -- its memory traffic alone)
-		nu = A.u0[S0] + (V)b4a;
-		nv = A.v0[S0] + (V)b4b;
+		nu = P[0].u0[S0] + (V)b4[0];
+		nv = P[0].v0[S0] + (V)b4[STEPS - 1];
 #else
-		stages(A, p, kk, std::integral_constant<int, (FED < 8 ? FED : 8)>{}, 0, b4a, nu, nv, EA, std::integral_constant<int, 0>{});  // step n: the new row p - 4 ...
+		// step n of the launch: the new row p - 4 (n + 1), which is the next pipeline's newest row (same slot: rows shifted by 4)
+		for_sequence(
+		    [&](auto nn) {
+			    constexpr int N = decltype(nn)::value;
+#ifdef CRD_PROBE_HALFMATH
+			    if constexpr (N > 0) return;
 #endif
-#if !defined(CRD_PROBE_HALFMATH) && !defined(CRD_PROBE_NOMATH)
-		B.u0[S0] = nu;                            // ... is the second pipeline's newest row (same slot: rows shifted by 4)
-		B.v0[S0] = nv;
-		B.bq[S0] = b4a;
-		if constexpr (COOP) edge_publish<(K & 1) * kEdgeParityBytes + 32>(edge_pub, nu);
-		stages(B, p - kApron, kk, std::integral_constant<int, (FED < 8 ? 0 : FED - 8)>{}, 4, b4b, nu, nv, EB, std::integral_constant<int, 4>{});  // step n + 1: the new row p - 8
+			    if constexpr (N > 0) {
+				    P[N].u0[S0] = nu;
+				    P[N].v0[S0] = nv;
+				    P[N].bq[S0] = b4[N - 1];
+				    if constexpr (COOP) edge_publish<(K & 1) * kEdgeParityBytes<STEPS> + 32 * N>(edge_pub, nu);
+			    }
+			    constexpr int live = FED - 8 * N < 0 ? 0 : (FED - 8 * N > 8 ? 8 : FED - 8 * N);
+			    stages(P[N], p - kApron * N, kk, std::integral_constant<int, live>{}, 4 * N, b4[N], nu, nv, E[N], std::integral_constant<int, 4 * N>{});
+		    },
+		    std::make_integer_sequence<int, STEPS>{});
 #endif
 		// (FHN fp64) From its stores to the next row's fill a wavefront issues ahead of its SIMD's other wavefronts (which are in their
 		// arithmetic): its memory operations go out when it reaches them instead of waiting their turn among vector instructions.
@@ -863,7 +927,7 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		// or a column beyond nx) is parked on an offset beyond the buffer resource's range, where the hardware drops its write; under an
 		// `if (lane_stores)` the compiler puts a skip branch (s_cbranch_execz) in front of the stores, a wavefront without a storing lane
 		// then has fewer operations in flight than the wait assumes, and its ring read can overtake the LDS-DMA fill of its slot.
-		if constexpr (FED >= 4 * kApron) {
+		if constexpr (FED >= FILL) {
 #ifndef CRD_PROBE_NOSTORE
 			buffer_row_store<NT>(row_resource(out_row_u), xb_store, nu);
 			buffer_row_store<NT>(row_resource(out_row_v), xb_store, nv);
@@ -878,7 +942,7 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		out_row_v += nx;
 		// (COOP) what the block's wavefronts published during this iteration is complete beyond the barrier; the reads of what the next
 		// iteration needs of it go out at once and land while that iteration waits for its row
-		if constexpr (COOP) edge_exchange<(K & 1) * kEdgeParityBytes>(edge_con, e01, e23, e45, e67);
+		if constexpr (COOP) edge_exchange<(K & 1) * kEdgeParityBytes<STEPS>>(edge_con, edge);
 	};
 	auto next_trip = [&]() {
 		if constexpr (kRingRows > M) {
@@ -887,21 +951,21 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 		}
 	};
 	int m = 0;
-	for_sequence(  // the pipeline fills (a chunk has at least one row: sixteen iterations and more)
+	for_sequence(  // the pipeline fills (a chunk has at least one row: FILL iterations and more)
 	    [&](auto i) {
 		    constexpr int I = decltype(i)::value;
 		    iteration(I, std::integral_constant<int, I % M>{}, i);
 		    if constexpr (I % M == M - 1) next_trip();
 	    },
-	    std::make_integer_sequence<int, 4 * kApron>{});
-	m = 4 * kApron;
+	    std::make_integer_sequence<int, FILL>{});
+	m = FILL;
 	for (; m + M - 1 < niter; m += M) {
-		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::integral_constant<int, 4 * kApron>{}); }, std::make_integer_sequence<int, M>{});
+		for_sequence([&](auto k) { iteration(m + decltype(k)::value, k, std::integral_constant<int, FILL>{}); }, std::make_integer_sequence<int, M>{});
 		next_trip();
 	}
 	for_sequence(
 	    [&](auto k) {
-		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::integral_constant<int, 4 * kApron>{});
+		    if (m + decltype(k)::value < niter) iteration(m + decltype(k)::value, k, std::integral_constant<int, FILL>{});
 	    },
 	    std::make_integer_sequence<int, M - 1>{});
 	// the fills still in flight write LDS: they must have landed before the wavefront ends and its LDS goes to the next workgroup
@@ -915,11 +979,11 @@ __device__ __forceinline__ void fused_item_two_steps(const Slab<Real> &s, const 
 // STEPS = 2: two steps per launch (fused_item_two_steps).
 // Wavefronts per SIMD the register allocator is held to: the two-step pipelines live at the 168-register line (three wavefronts).
 template <typename Real, int MODEL, int COLS, int STEPS, bool ABSORB>
-constexpr int kMinWaves = (STEPS == 2 && COLS * (int)sizeof(Real) == 8 && MODEL == CRD_MODEL_FHN && !ABSORB) ? 3 : 1;
+constexpr int kMinWaves = (STEPS == 2 && COLS * (int)sizeof(Real) == 8 && MODEL == CRD_MODEL_FHN && !ABSORB) ? 3 : (STEPS == 3 ? 2 : 1);
 template <typename Real, int MODEL, bool ABSORB, int EMBED, int COLS, bool NT = false, int STEPS = 1>
 __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) __attribute__((amdgpu_waves_per_eu(kMinWaves<Real, MODEL, COLS, STEPS, ABSORB>))) crd_rk4_fused_step_kernel(Slab<Real> s, FusedArgs<Real> a)
 {
-	static_assert(STEPS == 1 || (STEPS == 2 && EMBED == 0), "two steps per launch: the plain step only");
+	static_assert(STEPS == 1 || ((STEPS == 2 || STEPS == 3) && EMBED == 0), "several steps per launch: the plain step only");
 	// The work item is a property of the wavefront: keep it (and everything derived from it: rows, trip counts, the
 	// per-row table reads, the boundary-row tests) in scalar registers.
 	// Optional remap: blocks are dealt round-robin over the 8 XCDs; the remap gives each XCD one contiguous run of items.
@@ -949,9 +1013,9 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) __attribute__((amdg
 	const int chunk = __builtin_amdgcn_readfirstlane(cblk);
 	if (strip >= a.nstrips || chunk >= a.nchunks) return;  // (a barrier waits for the surviving wavefronts of the workgroup only)
 	// the row rings of a two-step launch's wavefronts (fused_item_two_steps)
-	__shared__ __attribute__((aligned(16))) char rings[STEPS == 2 ? kRingBytes<Real, COLS> : 16];
+	__shared__ __attribute__((aligned(16))) char rings[STEPS >= 2 ? kRingBytes<Real, COLS, STEPS> : 16];
 	lds_char *const block_rings = (lds_char *)rings;
-	__shared__ __attribute__((aligned(16))) char edges[(STEPS == 2 && kCoop<Real, MODEL, COLS>) ? kEdgeBytes + kEdgeDumpBytes : 16];
+	__shared__ __attribute__((aligned(16))) char edges[(STEPS >= 2 && kCoop<Real, MODEL, COLS, STEPS>) ? kEdgeBytes<STEPS> + kEdgeDumpBytes<STEPS> : 16];
 	lds_char *const block_edges = (lds_char *)edges;
 	if constexpr (ABSORB) {
 		// Does any row this chunk's pipeline touches -- [j0 - APRON, j1 + APRON) -- map to global row 0 or ny - 1?  The two are
@@ -962,15 +1026,15 @@ __global__ void __launch_bounds__(kLanes *kMaxWavesPerBlock) __attribute__((amdg
 		const int j1 = (j0 + a.chunk < a.r_end[range]) ? j0 + a.chunk : a.r_end[range];
 		const int lo = a.js + j0 - APRON, hi1 = a.js + j1 + APRON;  // (lo > -ny and hi1 < 3 ny: a slab is at most the grid, ghost rows at most a slab)
 		const bool touches = (lo <= 0 && 0 <= hi1) || (lo <= a.ny && a.ny <= hi1) || (lo <= 2 * a.ny && 2 * a.ny <= hi1);
-		if constexpr (STEPS == 2) {
-			if (touches) fused_item_two_steps<Real, MODEL, true, COLS, NT>(s, a, strip, chunk, block_rings, sblk, block_edges);
-			else fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk, block_rings, sblk, block_edges);
+		if constexpr (STEPS >= 2) {
+			if (touches) fused_item_multi_step<Real, MODEL, true, COLS, NT, STEPS>(s, a, strip, chunk, block_rings, sblk, block_edges);
+			else fused_item_multi_step<Real, MODEL, false, COLS, NT, STEPS>(s, a, strip, chunk, block_rings, sblk, block_edges);
 		} else {
 			if (touches) fused_item<Real, MODEL, true, EMBED, COLS, NT>(s, a, strip, chunk);
 			else fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
 		}
-	} else if constexpr (STEPS == 2) {
-		fused_item_two_steps<Real, MODEL, false, COLS, NT>(s, a, strip, chunk, block_rings, sblk, block_edges);
+	} else if constexpr (STEPS >= 2) {
+		fused_item_multi_step<Real, MODEL, false, COLS, NT, STEPS>(s, a, strip, chunk, block_rings, sblk, block_edges);
 	} else {
 		fused_item<Real, MODEL, false, EMBED, COLS, NT>(s, a, strip, chunk);
 	}
@@ -1031,9 +1095,16 @@ int resident_wavefronts()
 	return slots;
 }
 
+// Three steps per launch (round 6): FHN in fp64, one column per lane, the block as the strip -- the one kernel whose launch is bound by
+// its memory traffic rather than by issue.
+template <typename Real, int MODEL>
+constexpr bool kCanThreeSteps = sizeof(Real) == 8 && MODEL == CRD_MODEL_FHN;
+
 template <typename Real, int MODEL>
 int resident_wavefronts(int cols, int steps = 1)
 {
+	if constexpr (kCanThreeSteps<Real, MODEL>)
+		if (steps == 3) return resident_wavefronts<Real, MODEL, 1, 3>();
 	if constexpr (MODEL != kModelDiffusionOnly)  // (the diffusion-only variant has no two-step instantiation)
 		if (steps == 2) return cols == 2 ? resident_wavefronts<Real, MODEL, 2, 2>() : resident_wavefronts<Real, MODEL, 1, 2>();
 	return cols == 2 ? resident_wavefronts<Real, MODEL, 2, 1>() : resident_wavefronts<Real, MODEL, 1, 1>();
@@ -1047,7 +1118,7 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols, int steps 
 	// Two steps per launch: 16 fill rows per chunk instead of 8, and a pipeline bound by issue, not by the memory system: 128-row
 	// chunks (8192^2 fp64: 48 rows 0.301 ms per step, 64 0.289, 96 0.278, 128 0.267, 192 0.276, 256 0.276; fp32 alike,
 	// profiles/r04/two_step_tune.txt); chunk mode 2 is the 64-row alternative there.
-	int chunk = steps == 2 ? (chunk_mode == 2 ? 64 : 128) : 32;
+	int chunk = steps == 3 ? (chunk_mode == 2 ? 96 : 192) : steps == 2 ? (chunk_mode == 2 ? 64 : 128) : 32;  // (three steps: 24 fill rows per chunk)
 	while (chunk > 8 && (long)nstrips * ((rows + chunk - 1) / chunk) < (long)slots) chunk /= 2;
 	// Tiny launches: where even 8-row chunks make fewer blocks than half the CUs, 4-row chunks put twice as many CUs to work (256^2:
 	// 7.3 -> 6.4 us per step; the reference's 100 x 400 Goldbeter grid: 8.2 -> 6.5).  With more blocks than that the extra apron rows
@@ -1060,7 +1131,7 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols, int steps 
 		const long need = fit >= 1 ? (rows + fit - 1) / fit : 0;
 		if (need > chunk && need <= 96) chunk = (int)need;
 	}
-	if (one_round && steps == 2) {
+	if (one_round && steps >= 2) {
 		// Two steps per launch are bound by issue, and what a launch loses is its last, partly filled round of resident blocks: chunks
 		// such that the launch is just under a WHOLE NUMBER of rounds -- the fewest rounds whose chunks stay within 288 rows (longer
 		// ones have fewer fill rows per row; 8192^2 fp64: 128 rows = 3.6 rounds 0.2667 ms per step, 155 = 2.97 rounds 0.2617, 235 =
@@ -1071,7 +1142,7 @@ int fused_chunk_rows(int nstrips, int rows, int chunk_mode, int cols, int steps 
 			const long chunks = k * resident_blocks / strip_blocks;
 			if (chunks < 1) continue;
 			const long need = (rows + chunks - 1) / chunks;
-			if (need <= 288) {
+			if (need <= (steps == 3 ? 432 : 288)) {
 				if (need >= 16) chunk = (int)need;
 				break;
 			}
@@ -1112,7 +1183,11 @@ constexpr PlanCandidate kPlanCandidates[] = {
     {0, 0, 2, 1}, {0, 1, 2, 1}, {0, 2, 2, 1}, {1, 0, 2, 1}, {1, 1, 2, 1}, {2, 0, 2, 1}, {2, 1, 2, 1}, {2, 2, 2, 1},
     // fifth dimension (round 4): two steps per launch (128-row chunks, or 64), non-temporal stores
     {0, 0, 1, 1, 2}, {0, 1, 1, 1, 2}, {0, 2, 1, 1, 2}, {1, 0, 1, 1, 2}, {1, 1, 1, 1, 2}, {2, 1, 1, 1, 2},
-    {0, 0, 2, 1, 2}, {0, 1, 2, 1, 2}, {0, 2, 2, 1, 2}, {1, 0, 2, 1, 2}, {1, 1, 2, 1, 2}, {2, 1, 2, 1, 2}};
+    {0, 0, 2, 1, 2}, {0, 1, 2, 1, 2}, {0, 2, 2, 1, 2}, {1, 0, 2, 1, 2}, {1, 1, 2, 1, 2}, {2, 1, 2, 1, 2},
+    // sixth (round 6): three steps per launch, the block as the strip (FHN fp64: kCanThreeSteps), non-temporal stores
+    // (whole-rounds chunks win by 7 % -- 293 rows = two rounds of resident blocks on 8192^2 against 192 rows = three and a bit --, plain
+    // stores by half a per cent on some boxes)
+    {0, 0, 1, 1, 3}, {0, 1, 1, 1, 3}, {0, 2, 1, 1, 3}, {1, 0, 1, 1, 3}, {1, 1, 1, 1, 3}, {1, 0, 1, 0, 3}, {1, 1, 1, 0, 3}};
 constexpr int kNumPlanCandidates = (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]);
 
 template <typename Real, int MODEL>
@@ -1120,11 +1195,20 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
                           hipStream_t st)
 {
 	clear_launch_status();
-	if (row_end <= row_begin) return hipSuccess;
+	if (row_end <= row_begin) {
+		// nothing to launch: the events a caller bound to the launch are recorded on the stream instead, so that a wait on them sees
+		// this call and not an earlier one
+		if (c.geometry) return hipSuccess;
+		if (c.start_event)
+			if (hipError_t e = hipEventRecord(c.start_event, st); e != hipSuccess) return e;
+		if (c.done_event)
+			if (hipError_t e = hipEventRecord(c.done_event, st); e != hipSuccess) return e;
+		return hipSuccess;
+	}
 	if (row_end2 < row_begin2) row_end2 = row_begin2;
 	// Two steps per launch: plain steps only, and not the diffusion-only variant (no instantiation: that model is a plumbing case).
 	constexpr bool kCanTwoSteps = MODEL != kModelDiffusionOnly;
-	if (c.steps != 1 && (c.steps != 2 || c.embed || !kCanTwoSteps)) return hipErrorInvalidValue;
+	if (c.steps != 1 && (c.embed || !((c.steps == 2 && kCanTwoSteps) || (c.steps == 3 && kCanThreeSteps<Real, MODEL>)))) return hipErrorInvalidValue;
 	// rows may extend into the ghost region (deep-halo steps), but the pipeline reads kStepHalo rows per step beyond them
 	if (!d.wrap && (row_begin < -(kGhost - c.steps * kStepHalo) || row_end > d.nyl + (kGhost - c.steps * kStepHalo))) return hipErrorInvalidValue;
 	const Slab<Real> s = typed<Real>(d);
@@ -1139,6 +1223,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	a.h1 = (Real)c.dt;
 	for (int k = 0; k < 5; k++) a.absorb[k] = c.absorb[k];
 	for (int k = 0; k < 4; k++) a.absorb2[k] = c.absorb2[k];
+	for (int k = 0; k < 4; k++) a.absorb3[k] = c.absorb3[k];
 	a.js = js;
 	a.ny = ny;
 	const int rows = row_end - row_begin, rows2 = row_end2 - row_begin2;
@@ -1164,7 +1249,8 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	// the reaction block of a diffusion-only run is skipped, absorbing rows included (src/GoldbeterModel_torus.cpp:668)
 	constexpr bool kCanAbsorb = MODEL != kModelDiffusionOnly;
 	const bool absorb1 = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3] || (c.embed && c.absorb[4]));
-	const bool absorb12 = absorb1 || (kCanAbsorb && (c.absorb2[0] || c.absorb2[1] || c.absorb2[2] || c.absorb2[3]));
+	const bool absorb12 = absorb1 || (kCanAbsorb && (c.absorb2[0] || c.absorb2[1] || c.absorb2[2] || c.absorb2[3])) ||
+	                      (kCanAbsorb && c.steps == 3 && (c.absorb3[0] || c.absorb3[1] || c.absorb3[2] || c.absorb3[3]));  // (any stage of any step of the launch)
 	const dim3 block(kLanes * sw);
 
 	int cols = cols_default, steps = 1;
@@ -1200,14 +1286,15 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		}
 	};
 	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0, int want_steps = 1) {
-		steps = (want_steps == 2 && kCanTwoSteps) ? 2 : 1;
+		steps = (want_steps == 3 && kCanThreeSteps<Real, MODEL>) ? 3 : (want_steps >= 2 && kCanTwoSteps) ? 2 : 1;
 		nt = want_nt != 0;
 		if (const char *e = tuning::knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0;
 		cols = (want_cols == 2 && cols2_ok) ? 2 : 1;
 		if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
+		if (steps == 3) cols = 1;  // (the three-step pipeline: one column per lane)
 		const int valid = cols * kLanes - 2 * steps * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
 		a.nstrips = (d.nx + valid - 1) / valid;
-		if (steps == 2 && cols == 1 && kCoop<Real, MODEL, 1>) {  // the block as the strip: one apron around its sw wavefronts
+		if ((steps == 2 && cols == 1 && kCoop<Real, MODEL, 1, 2>) || (steps == 3 && kCoop<Real, MODEL, 1, 3>)) {  // the block as the strip: one apron around its sw wavefronts
 			const int block_valid = sw * kLanes - 2 * steps * kApron;
 			a.nstrips = sw * ((d.nx + block_valid - 1) / block_valid);
 		}
@@ -1242,15 +1329,17 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 			// plain step: absorbing rows x columns per lane x store hint x steps per launch, all compile-time
 			bool last_launch = true, first_launch = true;  // (of this call: the ones a done_event / a start_event is bound to)
 			auto with = [&](auto absorb_c, auto cols_c, auto nt_c, auto steps_c) {
+				constexpr int kSteps = decltype(steps_c)::value;
 				auto kernel = crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value,
-				                                        kCanTwoSteps ? decltype(steps_c)::value : 1>;
+				                                        (kSteps == 3 ? kCanThreeSteps<Real, MODEL> && decltype(cols_c)::value == 1 : kCanTwoSteps) ? kSteps : 1>;
 				hipEvent_t e0 = first_launch ? c.start_event : nullptr, e1 = last_launch ? c.done_event : nullptr;
 				if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(a.nblocks), block, 0, st, e0, e1, 0, s, a);
 				else kernel<<<a.nblocks, block, 0, st>>>(s, a);
 				first_launch = false;
 			};
 			auto with_steps = [&](auto absorb_c, auto cols_c, auto nt_c) {
-				if (steps == 2) with(absorb_c, cols_c, nt_c, std::integral_constant<int, 2>{});
+				if (steps == 3) with(absorb_c, cols_c, nt_c, std::integral_constant<int, 3>{});
+				else if (steps == 2) with(absorb_c, cols_c, nt_c, std::integral_constant<int, 2>{});
 				else with(absorb_c, cols_c, nt_c, std::integral_constant<int, 1>{});
 			};
 			auto with_cols = [&](auto absorb_c, auto nt_c) {
@@ -1265,7 +1354,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (with_selects) with_nt(std::true_type{});
 				else with_nt(std::false_type{});
 			};
-			if (steps == 2 && absorb12) {
+			if (steps >= 2 && absorb12) {
 				// Two steps per launch with absorbing rows on.  The ABSORB kernel holds the body with the selects AND the one without
 				// (it decides per chunk), and the former's scalar registers spill into two vector registers of the whole kernel: 170
 				// VGPRs, two wavefronts per SIMD instead of three for EVERY item of the launch (+20 ... 38 % measured).  So the rows are
@@ -1279,7 +1368,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 					int cursor = want[2 * r];
 					const int end = want[2 * r + 1];
 					for (int g = -1; g <= 1 && cursor < end; g++) {  // local rows of global rows ny - 1 and 0, one period down / here / one up
-						const int jb = (ny - 1 - js) + g * ny, lo = std::max(cursor, jb - 2 * kApron), hi = std::min(end, jb + 2 + 2 * kApron);
+						const int jb = (ny - 1 - js) + g * ny, lo = std::max(cursor, jb - steps * kApron), hi = std::min(end, jb + 2 + steps * kApron);
 						if (lo >= hi) continue;
 						if (cursor < lo) {
 							if (n_without == 6) fits = false;
@@ -1317,7 +1406,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 					layout();
 				}
 			} else {
-				launch(steps == 2 ? absorb12 : absorb1);
+				launch(steps >= 2 ? absorb12 : absorb1);
 			}
 		}
 		return launch_status();
@@ -1363,6 +1452,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		// candidate must not win or lose by its place in the queue.
 		constexpr int kCandidates = kNumPlanCandidates, kRounds = 3;
 		const bool two_steps_ok = kCanTwoSteps && !c.embed && c.steps == 1 && d.nyl >= 4 * kStepHalo;  // (the caller steps pairs once the plan says so)
+		const bool three_steps_ok = two_steps_ok && kCanThreeSteps<Real, MODEL> && d.nyl >= 6 * kStepHalo && d.wrap;  // (... or triples: single slabs)
 		float t_best[kCandidates];
 		bool live[kCandidates];
 		int reps = 3;
@@ -1370,7 +1460,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 			t_best[k] = 0.f;
 			configure(kPlanCandidates[k].one_round, kPlanCandidates[k].remap, kPlanCandidates[k].cols, kPlanCandidates[k].nt, kPlanCandidates[k].steps);
 			live[k] = k == 0 || !(kPlanCandidates[k].one_round && a.chunk == fused_chunk_rows<Real, MODEL>(a.nstrips, rows, 0, cols, steps));  // (same as a 32-row plan)
-			if (live[k] && kPlanCandidates[k].steps != (two_steps_ok ? steps : 1)) live[k] = false;  // (two steps per launch: plain steps)
+			if (live[k] && kPlanCandidates[k].steps != ((kPlanCandidates[k].steps == 3 ? three_steps_ok : two_steps_ok) ? steps : 1)) live[k] = false;  // (several steps per launch: plain steps)
 			if (live[k] && steps == 2 && cols == 2 && sizeof(Real) == 8) live[k] = false;  // (256 VGPRs, one wavefront per SIMD: measured 0.347 against 0.312 ms)
 			if (live[k] && kPlanCandidates[k].remap != a.remap) live[k] = false;  // (the mapping fell back to dispatch order)
 			if (live[k] && kPlanCandidates[k].cols != cols) live[k] = false;      // (two columns per lane not possible here, or pinned by a knob)
@@ -1467,7 +1557,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		const int apron = steps * (c.embed ? kApron + 1 : kApron);
 		g.real_bytes = (int)sizeof(Real);
 		g.model = MODEL;
-		g.absorb = steps == 2 ? 0 : (absorb1 ? 1 : 0);  // (two steps with absorbing rows on: the bulk goes out as the select-free kernel)
+		g.absorb = steps >= 2 ? 0 : (absorb1 ? 1 : 0);  // (several steps with absorbing rows on: the bulk goes out as the select-free kernel)
 		g.embed = c.embed;
 		g.cols = cols;
 		g.nt = nt ? 1 : 0;
@@ -1481,7 +1571,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		g.iterations_per_trip = c.embed ? CRD_EMBED_SLOTS : 4;
 		g.lanes = kLanes;
 		g.lanes_valid = (cols * kLanes - 2 * apron) / cols;
-		if (steps == 2 && cols == 1 && kCoop<Real, MODEL, 1>) g.lanes_valid = (sw * kLanes - 2 * apron) / sw;  // the block as the strip: 60 of 64 on average
+		if ((steps == 2 && cols == 1 && kCoop<Real, MODEL, 1, 2>) || (steps == 3 && kCoop<Real, MODEL, 1, 3>)) g.lanes_valid = (sw * kLanes - 2 * apron) / sw;  // the block as the strip: 60 (58) of 64 on average
 		g.mapping = a.remap;
 		g.wave_iterations = (long)a.nstrips * ((long)(rows + rows2) + (long)a.nchunks * 2 * apron);
 		return hipSuccess;

@@ -25,7 +25,7 @@ constexpr double kFhnReactionRate = 10.0, kGoldbeterReactionRate = 400.0;
 constexpr int kStepHalo = 4;
 // Fused steps between two halo exchanges of a multi-slab run (the exchange period E): the exchange moves kStepHalo * E ghost rows
 // and each slab recomputes the shrinking ghost region redundantly in between (communication-avoiding deep halo).  A property of
-// the run, chosen at run time (crd_set_exchange_period; bench.py rehearses 8 and 16 on the machine at hand): 8 against 4 measured
+// the run, chosen at run time (crd_set_exchange_period; bench.py rehearses 8, 10 and 16 on the machine at hand): 8 against 4 measured
 // 0.9-1.6 % faster on 1024- to 4096-row slabs of an 8192-column grid on a world-size-1 ring; 16 halves the fixed cost per step of
 // a cycle again (two small launches, two cross-stream waits) for 3 % more redundant rows on a 1024-row share.
 constexpr int kMinExchangeEvery = 3;  // the multi-slab fused stepper splits the first and the last step of a cycle

@@ -93,7 +93,8 @@ struct FusedCall {
 	double dt;
 	int absorb[5];  // four stages + the embedded pair's fifth (embed = 1: t + dt; embed = 2: t + 3/4 dt)
 	int absorb2[4] = {0, 0, 0, 0};  // the stages of the step after this one (t + dt + c_k dt): read by a two-step launch
-	int steps = 1;  // 2: this launch advances the rows by TWO steps (single slab, no second row range, no error estimate)
+	int absorb3[4] = {0, 0, 0, 0};  // ... and of the one after that ((t + dt) + dt + c_k dt): a three-step launch
+	int steps = 1;  // 2 / 3: this launch advances the rows by TWO / THREE steps (no error estimate; three: single slabs, FHN fp64)
 	Planes y0;
 	Planes yout;
 	// embedded error estimate (adaptive stepping): weighted square sum of the local error over the launch's rows
@@ -133,6 +134,7 @@ int fused_default_columns(int precision, int nx);  // columns per lane of launch
 int fused_plan_candidates();                       // the plans the tuner times (crd_launch_plan_candidate)
 bool fused_plan_candidate(int index, int *chunk_mode, int *mapping, int *cols, int *nt, int *steps);
 bool fused_two_steps_supported(const SlabDesc &d);
+int fused_steps_supported(int precision, const SlabDesc &d, int want);  // steps per launch a plan that asks for `want` gets on this slab
 int fused_max_items(const SlabDesc &d);
 
 // Layout adaptors between the AoS boundary layout (host precision: f64 or device precision) and SoA planes.

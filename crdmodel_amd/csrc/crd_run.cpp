@@ -325,18 +325,11 @@ int main(int argc, char *argv[])
 		cleanup();
 		return 1;
 	}
-	if (G > 1 && d0 == 1) {
-		// exchange period of the one-launch stepper: the ini's, or 16 steps where every slab is tall enough for its 64-row bands to be split
-		// off (one rank's share of an 8192^2 run through a self-ring: 48 against 52 us per step), else the library's 8
-		int64_t shortest = INT64_MAX;
-		for (int k = 0; k < G; k++) {
-			int64_t a, b;
-			crd_get_slab(ctx[(size_t)k], &a, &b);
-			shortest = std::min<int64_t>(shortest, b - a + 1);
-		}
-		const int period = cfg.exchange_period ? cfg.exchange_period : (shortest >= 256 ? 16 : 8);
+	if (G > 1 && d0 == 1 && cfg.exchange_period) {
+		// exchange period of the one-launch stepper: the ini's; without one the contexts keep what crd_create chose (10 steps where every
+		// slab has 256 rows or more, else 8: include/crd.h, crd_set_exchange_period)
 		for (int k = 0; k < G; k++)
-			if ((rc = crd_set_exchange_period(ctx[(size_t)k], period)) != CRD_OK) {
+			if ((rc = crd_set_exchange_period(ctx[(size_t)k], cfg.exchange_period)) != CRD_OK) {
 				die("crd_set_exchange_period", rc, ctx[(size_t)k]);
 				cleanup();
 				return 1;

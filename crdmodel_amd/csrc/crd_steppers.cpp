@@ -239,6 +239,15 @@ bool pair_is_exact(const crd_ctx *c, double t0, int64_t s, double dt)
 		if (absorbing(c, t2 + cs4[k] * dt) != absorbing(c, (t + dt) + cs4[k] * dt)) return false;
 	return true;
 }
+// ... and steps s, s + 1, s + 2 as one three-step launch: the third step's flags come from (t + dt) + dt.
+bool triple_is_exact(const crd_ctx *c, double t0, int64_t s, double dt)
+{
+	if (!pair_is_exact(c, t0, s, dt)) return false;
+	const double t = t0 + (double)s * dt, t3 = t0 + (double)(s + 2) * dt, cs4[4] = {0.0, 0.5, 0.5, 1.0};
+	for (int k = 0; k < 4; k++)
+		if (absorbing(c, t3 + cs4[k] * dt) != absorbing(c, ((t + dt) + dt) + cs4[k] * dt)) return false;
+	return true;
+}
 
 // RCCL runs: one decision for the whole ring on where in the exchange cycle the call starts (see crd_ctx::agree_dev).  begin_
 // enqueues the reduction on the comm stream and returns; finish_ waits for it.  Every rank of the run makes both calls in every
@@ -296,6 +305,7 @@ FusedCall make_fused_call(const crd_ctx *c, double t, double dt, int src, int ds
 	const double cs[4] = {0.0, 0.5, 0.5, 1.0};
 	for (int k = 0; k < 4; k++) call.absorb[k] = absorbing(c, t + cs[k] * dt) ? 1 : 0;
 	for (int k = 0; k < 4; k++) call.absorb2[k] = absorbing(c, (t + dt) + cs[k] * dt) ? 1 : 0;  // the step after this one, as the stepping loop forms its time
+	for (int k = 0; k < 4; k++) call.absorb3[k] = absorbing(c, ((t + dt) + dt) + cs[k] * dt) ? 1 : 0;  // ... and the one after that (three-step launches)
 	call.absorb[4] = call.absorb[3];  // (the embedded pairs' fifth stage: set by the adaptive integrator)
 	call.y0 = c->planes(src);
 	call.yout = c->planes(dst);
@@ -313,6 +323,8 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 	const int stepper = resolve_stepper(lead);
 	if (stepper < 0) return fail(lead, CRD_EINVAL, "fused stepper not available for this configuration");
 	for (int k = 0; k < n; k++) cs[k]->dense.pending = cs[k]->ark.live = false;  // stepping on from the state handed back, not from the integrator's internal one
+	if (nsteps > 0)
+		for (int k = 0; k < n; k++) cs[k]->last_step_t = t0 + (double)(nsteps - 1) * dt, cs[k]->last_step_dt = dt;
 	if (stepper != CRD_STEPPER_FUSED)
 		for (int k = 0; k < n; k++) cs[k]->cycle_pos = -1;  // the staged stepper keeps one ghost row of one field current, not the deep halo
 	for (int k = 0; k < n; k++)
@@ -343,13 +355,15 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			hipEvent_t *kb = nullptr, *ke = nullptr;
 			// The plan may say "two steps per launch" (measured, or pinned): pairs while two steps are left, a single-step launch
 			// for an odd last one (pair_is_exact: see there).
-			const bool pairing = stepper == CRD_STEPPER_FUSED && c->plan.tuned && c->plan.steps == 2 && fused_two_steps_supported(c->desc);
-			int rc, took = (pairing && s + 2 <= nsteps && pair_is_exact(c, t0, s, dt)) ? 2 : 1;
+			const int per_launch = (stepper == CRD_STEPPER_FUSED && c->plan.tuned) ? fused_steps_supported(c->p.precision, c->desc, c->plan.steps) : 1;
+			const bool pairing = per_launch >= 2;
+			// (a three-step plan: triples while three steps are left, then a pair or a single step)
+			int rc, took = (per_launch == 3 && s + 3 <= nsteps && triple_is_exact(c, t0, s, dt)) ? 3 : (pairing && s + 2 <= nsteps && pair_is_exact(c, t0, s, dt)) ? 2 : 1;
 			// every fourth step at most: an event pair around EVERY launch of a short run would sit inside the region being timed.  Only
 			// launches of the plan's own kind are timed (a pairing plan's odd last step, or a pair stepped singly, goes out as a one-step
 			// launch: another kernel, which must not enter the average; runs too short to hold a pair time what there is).
 			const int64_t want = std::min<int64_t>(kMaxTimedLaunches, std::max<int64_t>(1, nsteps / 4));
-			const int kind = (pairing && nsteps >= 2) ? 2 : 1;
+			const int kind = (per_launch == 3 && nsteps >= 3) ? 3 : (pairing && nsteps >= 2) ? 2 : 1;
 			if (timed_launches && timed < want && took == kind && (s * want / std::max<int64_t>(nsteps, 1)) >= timed && ((s % 4) >= 1 || nsteps < 4)) {
 				kb = &c->ev_k[(size_t)(2 * timed)];
 				ke = &c->ev_k[(size_t)(2 * timed + 1)];
@@ -408,7 +422,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		// Two steps per launch where the lead context's plan says so (measured, or pinned): pairs that do not straddle an exchange.
 		// Where the exchanges fall in the step sequence does not depend on the pairing, so the ranks of a ring / the threads of a group
 		// may pair differently (each by its own plan) and still meet at the same collectives.
-		bool pairs = fused && lead->plan.tuned && lead->plan.steps == 2;
+		bool pairs = fused && lead->plan.tuned && lead->plan.steps >= 2;  // (a three-step plan steps pairs inside an exchange cycle)
 		for (int k = 0; k < n; k++) pairs = pairs && fused_two_steps_supported(cs[k]->desc);
 		for (int64_t s = 0; s < nsteps;) {
 			const int q = (int)((s + q0) % E);

@@ -399,7 +399,34 @@ def plan_key(model, precision, plan):
     if isinstance(plan, dict):
         plan = (plan["one_round"], plan["xcd_mapping"], plan["columns_per_lane"], plan["nontemporal_stores"], plan.get("steps_per_launch", 1))
     key = "fused/%s/%s/chunk%d/map%d/cols%d/%s" % (model, precision, plan[0], plan[1], plan[2], "nt" if plan[3] else "plain")
-    return key + ("/steps2" if len(plan) > 4 and plan[4] == 2 else "")
+    return key + ("/steps%d" % plan[4] if len(plan) > 4 and plan[4] >= 2 else "")
+
+
+def kernel_table_digest():
+    """crd_kernel_table_digest: 16 hex digits over the step kernels of the loaded library ("" for a build without the table)."""
+    return lib().crd_kernel_table_digest().decode()
+
+
+def kernel_digest(geometry):
+    """16 hex digits over what the build's kernel table says about ONE kernel -- the one `geometry` (Slab.launch_geometry()) describes:
+    registers, LDS, scratch, occupancy and the instruction mix of its steady-state loop.  profiles/pmc_traffic.json and plan_stats.json
+    stamp every entry with the digest of the kernel it was measured on; bench.py quotes an entry only while the loaded library's kernel
+    still has that digest (a changed kernel makes its own entries stale, not the other kernels')."""
+    import hashlib
+
+    fields = ("vgprs", "sgprs", "lds_bytes", "scratch_bytes", "wavefronts_per_simd", "loop_valu", "loop_salu", "loop_vmem", "loop_lds", "loop_instructions", "exec_skipped_vmem")
+    if not geometry or not geometry.get("vgprs"):
+        return ""
+    return hashlib.sha256(",".join("%s=%d" % (f, int(geometry[f])) for f in fields).encode()).hexdigest()[:16]
+
+
+def kernel_digest_of_table_row(row):
+    """The same digest from a row of csrc/build/kernel_table.json (tools/kernel_regs.py --json): what a build's kernel would report
+    through crd_get_launch_geometry, without a device (tests/test_profiles.py)."""
+    lp = row["loop"]
+    return kernel_digest({"vgprs": row["vgprs"], "sgprs": row["sgprs"], "lds_bytes": row["lds_bytes"], "scratch_bytes": row["scratch_bytes"], "wavefronts_per_simd": row["wavefronts_per_simd"],
+                          "loop_valu": lp["valu"], "loop_salu": lp["salu"], "loop_vmem": lp["vmem"], "loop_lds": lp["lds"], "loop_instructions": lp["total"],
+                          "exec_skipped_vmem": row.get("exec_skipped_vmem", 0)})
 
 
 def rccl_unique_id():

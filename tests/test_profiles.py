@@ -21,8 +21,10 @@ def test_every_plan_candidate_has_a_pmc_traffic_entry_and_a_kernel_trace_record(
     # the headline workload (BASELINE.json: FHN 8192^2 fp64) and the other two kernels BASELINE's configurations run (C4 Goldbeter fp64, C5 FHN fp32)
     for model, precision in (("fhn", "f64"), ("goldbeter", "f64"), ("fhn", "f32")):
         for plan in plans:
+            if plan[4] == 3 and (model, precision) != ("fhn", "f64"):
+                continue  # (the three-step kernel is FHN fp64's: elsewhere such a plan steps pairs and reports the two-step key)
             key = crd.plan_key(model, precision, plan)
-            assert key in traffic, "no rocprofv3 --pmc passes recorded for %s (tools/jobs/r05_sweep.sh)" % key
+            assert key in traffic, "no rocprofv3 --pmc passes recorded for %s (tools/jobs/r06_sweep.sh)" % key
             rec = traffic[key]
             real = 8 if precision == "f64" else 4
             # read + write of both fields once is the least a launch can move; the aprons and strip edges add to it
@@ -30,6 +32,43 @@ def test_every_plan_candidate_has_a_pmc_traffic_entry_and_a_kernel_trace_record(
             assert abs(rec["write_bytes_per_point"] - 2 * real) <= 0.05 * 2 * real, (key, rec)  # every point of both fields is written exactly once
             assert os.path.exists(os.path.join(ROOT, rec["source"])), rec["source"]
             assert key in stats and stats[key]["sweep_trace_avg_us"] > 0, key
+
+
+def _table_rows():
+    path = os.path.join(ROOT, "crdmodel_amd", "csrc", "build", "kernel_table.json")
+    if not os.path.exists(path):
+        pytest.skip("no kernel table beside the library (a build with KERNEL_TABLE=0)")
+    return {(k["precision"], k["model"], k["absorb"], k["embed"], k["cols"], k["nt"], k["steps"]): k for k in json.load(open(path))["kernels"]}
+
+
+def test_profile_records_of_the_headline_plans_describe_the_kernels_of_this_build():
+    """Round 6 (the round-5 verdict's item 6): every entry of profiles/pmc_traffic.json / plan_stats.json carries the digest of the kernel
+    it was measured on (crdmodel_amd.kernel_digest: registers, occupancy and the loop's instruction mix as the assembler printed them),
+    and bench.py quotes an entry only while the loaded library's kernel has that digest -- a record of an older kernel build is dropped
+    (`traffic: null` with the reason), not quoted.  Here, without a device: the digests of THIS build's kernels, from the kernel table
+    the build keeps beside the library, against the records of every FHN fp64 plan (the headline workload: whatever plan the tuner picks
+    there must find current records) and of the other two BASELINE kernels' plans."""
+    import bench
+    import crdmodel_amd as crd
+
+    rows = _table_rows()
+    traffic, stats = _table("pmc_traffic.json"), _table("plan_stats.json")
+    models = {"fhn": 0, "goldbeter": 1}
+    for model, precision in (("fhn", "f64"), ("goldbeter", "f64"), ("fhn", "f32")):
+        for plan in crd.launch_plan_candidates():
+            if plan[4] == 3 and (model, precision) != ("fhn", "f64"):
+                continue
+            cols = plan[2] if plan[4] != 3 else 1
+            want = crd.kernel_digest_of_table_row(rows[(precision, models[model], 0, 0, cols, plan[3], plan[4])])
+            key = crd.plan_key(model, precision, plan)
+            assert traffic[key].get("kernel_digest") == want, (key, traffic[key].get("kernel_digest"), want)
+            assert stats[key].get("kernel_digest") == want, (key, stats[key].get("kernel_digest"), want)
+            assert bench.measured_traffic(key, 1 << 20, want)[0] is not None
+    # a record of another kernel build is not quoted, and the reason is said
+    key = crd.plan_key("fhn", "f64", (1, 1, 1, 1, 3))
+    nbytes, why = bench.measured_traffic(key, 1 << 20, "0123456789abcdef")
+    assert nbytes is None and "another build" in why and "0123456789abcdef" in why
+    assert bench.stale_reason(stats[key], "0123456789abcdef", "x") and not bench.stale_reason(stats[key], stats[key]["kernel_digest"], "x")
 
 
 def test_bench_reads_the_committed_tables():
@@ -53,10 +92,10 @@ def test_pinned_bench_stats_reproduce_the_sweep_for_the_headline_workload():
     for plan in crd.launch_plan_candidates():
         rec = stats[crd.plan_key("fhn", "f64", plan)]
         if "bench_stats_avg_us" not in rec:
-            pytest.fail("no pinned bench.py --stats record for %s (tools/jobs/r05_plan_stats.sh)" % crd.plan_key("fhn", "f64", plan))
+            pytest.fail("no pinned bench.py --stats record for %s (tools/jobs/r06_plan_stats.sh)" % crd.plan_key("fhn", "f64", plan))
         assert rec["bench_stats_calls"] >= 100
         # (bench.py's figure is the average of a few dozen event-bracketed launches of the timed region, the profiler's of every launch
         # of the process: they agree to 2 % for most plans, 8 % at worst)
         assert abs(rec["bench_stats_avg_us"] - 1e3 * rec["bench_kernel_ms_events"]) <= 0.08 * rec["bench_stats_avg_us"], rec
-        if plan[4] == 2 and plan[2] == 1:  # the plans a run actually ends up with at this size
+        if plan[4] >= 2 and plan[2] == 1:  # the plans a run actually ends up with at this size
             assert abs(rec["bench_stats_avg_us"] - 1e3 * rec["bench_kernel_ms_events"]) <= 0.03 * rec["bench_stats_avg_us"], rec

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Pinned-plan timing of ONE build of libcrd (CRD_LIBRARY selects it; tools/build_variant.sh NAME -D... makes the variants): for every
-case in CASES ("model:precision:nx:ny,...") and every plan in PLANS ("mode.mapping.cols.nt.steps,...") three rounds of 80 timed steps,
+case in CASES ("model:precision:nx:ny,...") and every plan in PLANS ("mode.mapping.cols.nt.steps,...") three rounds of NSTEPS (80) timed steps,
 median and minimum ms per step; then 16 steps from the initial state under the last plan and the sha256 of the result -- builds that
 are meant to compute the same bits print the same digest.  The A/B records of profiles/r05/*_ab.txt are runs of this script, one
 after the other for each build, on one box.
@@ -24,8 +24,9 @@ for case in os.environ.get("CASES", "fhn:f64:8192:8192").split(","):
             for pl in plans:
                 slab.set_launch_plan(*pl)
                 slab.step_rk4(0.0, dt, 8)
-                ms, _, _ = slab.step_rk4_timed(0.0, dt, 80)
-                res.setdefault(pl, []).append(ms / 80)
+                nsteps = int(os.environ.get("NSTEPS", "80"))  # (96: whole pairs and whole triples)
+                ms, _, _ = slab.step_rk4_timed(0.0, dt, nsteps)
+                res.setdefault(pl, []).append(ms / nsteps)
         for pl in plans:
             print("%s %s %s %sx%s plan %r: median %.4f ms/step min %.4f" % (tag, model, prec, nx, ny, pl, statistics.median(res[pl]), min(res[pl])), flush=True)
         # bits: 16 steps from y0 under the first plan, checksum

@@ -25,9 +25,11 @@ def main():
         del traffic[k]
     traffic["_comment"] = ("HBM-side bytes per grid point per launch of the dominant kernel, from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes; FETCH doubled per "
                            "the gfx950 correction of /opt/skills/guides/MI355X_MICROARCH.md, calibrated in profiles/r01/pmc_calibration.json).  fused/<model>/<precision>/chunk<mode>/"
-                           "map<mapping>/cols<columns per lane>/<nt|plain>[/steps2]: one entry per launch plan the tuner can choose (crd_launch_plan_candidate), measured by pinning "
+                           "map<mapping>/cols<columns per lane>/<nt|plain>[/steps2|/steps3]: one entry per launch plan the tuner can choose (crd_launch_plan_candidate), measured by pinning "
                            "the plans in turn in one process (tools/plan_sweep.py, tools/jobs/r05_sweep.sh); bench.py reports the entry of the plan its run used.  A two-step launch "
-                           "(/steps2) moves its bytes once per TWO grid-point-steps.  tests/test_profiles.py fails when a candidate has no entry.")
+                           "(/steps2) moves its bytes once per TWO grid-point-steps, a three-step one (/steps3) once per three.  kernel_digest: the kernel the entry was measured on (registers and loop "
+                           "instruction mix as the assembler printed them, crdmodel_amd.kernel_digest); bench.py quotes an entry only while the loaded library's kernel has that digest.  "
+                           "tests/test_profiles.py fails when a candidate has no entry or the headline plans' entries are stale.")
     for path in a.sweeps:
         d = json.load(open(path))
         rel = os.path.relpath(os.path.abspath(path), ROOT)
@@ -35,11 +37,11 @@ def main():
         for key, r in d["plans"].items():
             if "bytes_per_point" in r:
                 traffic[key] = {"bytes_per_point": r["bytes_per_point"], "read_bytes_per_point": r["read_bytes_per_point"], "write_bytes_per_point": r["write_bytes_per_point"],
-                                "kernel_compulsory_bytes_per_point": 4.0 * real, "source": rel, "grid": d["grid"]}
+                                "kernel_compulsory_bytes_per_point": 4.0 * real, "source": rel, "grid": d["grid"], "kernel_digest": r.get("kernel_digest", "")}
             if "trace_us" in r:
                 stats.setdefault(key, {})
                 stats[key].update({"sweep_trace_avg_us": r["trace_us"]["avg"], "sweep_trace_min_us": r["trace_us"]["min"], "sweep_trace_max_us": r["trace_us"]["max"],
-                                   "sweep_launches": r["trace_us"]["launches"], "grid": d["grid"], "source": rel})
+                                   "sweep_launches": r["trace_us"]["launches"], "grid": d["grid"], "source": rel, "kernel_digest": r.get("kernel_digest", "")})
     for path in a.bench_stats:
         for key, r in json.load(open(path)).items():
             stats.setdefault(key, {}).update(r)

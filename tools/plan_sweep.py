@@ -24,7 +24,7 @@ def main():
     ap.add_argument("--model", default="fhn")
     ap.add_argument("--precision", default="f64")
     ap.add_argument("--steps", type=int, default=24)
-    ap.add_argument("--warm", type=int, default=4)
+    ap.add_argument("--warm", type=int, default=6)  # (whole pairs and whole triples, like --steps)
     ap.add_argument("--t-boundary", type=float, default=0.0)
     ap.add_argument("--plans", default="", help='only these plans: "mode,mapping,cols,nt,steps;..." (default: every candidate)')
     ap.add_argument("--out", default="")
@@ -35,6 +35,8 @@ def main():
     dt = 0.8 * crd.stable_dt(p)
     y0 = crd.initial_conditions(crd.run_config(p, wave_length=0.1, wave_width=0.5, wave_inside=0))
     plans = crd.launch_plan_candidates()
+    if not (a.model == "fhn" and a.precision == "f64"):
+        plans = [q for q in plans if q[4] != 3]  # (the three-step kernel: FHN fp64 only; elsewhere such a plan steps pairs)
     if a.plans:
         plans = [tuple(int(v) for v in q.split(",")) for q in a.plans.split(";") if q]
     recs = []
@@ -49,7 +51,7 @@ def main():
             ms, kms, _ = slab.step_rk4_timed(0.0, dt, a.steps)
             per = plan[4] if len(plan) > 4 else 1  # steps per launch: a two-step plan makes half the launches
             assert a.warm % per == 0 and a.steps % per == 0 and slab.launch_plan()["steps_per_launch"] == per
-            recs.append({"plan": list(plan), "key": crd.plan_key(a.model, a.precision, plan), "first_launch": first, "warm": a.warm // per, "launches": (a.warm + a.steps) // per,
+            recs.append({"plan": list(plan), "key": crd.plan_key(a.model, a.precision, plan), "kernel_digest": crd.kernel_digest(slab.launch_geometry()), "first_launch": first, "warm": a.warm // per, "launches": (a.warm + a.steps) // per,
                          "steps_per_launch": per, "ms_per_step_events": ms / a.steps, "kernel_ms_events": kms})
             first += (a.warm + a.steps) // per
             print("%-44s %.4f ms/step (events)" % (recs[-1]["key"], ms / a.steps), flush=True)

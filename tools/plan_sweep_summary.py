@@ -53,7 +53,7 @@ def main():
     a = ap.parse_args()
     meta = json.load(open(a.plans))
     plans, pts = meta["plans"], meta["points"]
-    res = {p["key"]: {"plan": p["plan"], "grid": meta["grid"], "steps_per_launch": p.get("steps_per_launch", 1)} for p in plans}
+    res = {p["key"]: {"plan": p["plan"], "grid": meta["grid"], "steps_per_launch": p.get("steps_per_launch", 1), "kernel_digest": p.get("kernel_digest", "")} for p in plans}
 
     def counter(path, name):
         return per_plan(plans, step_dispatches(path, lambda r: float(r["Counter_Value"]) if r["Counter_Name"] == name else None))

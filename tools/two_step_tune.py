@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Chunk heights / mappings of the two-steps-per-launch kernel, on a TUNING build (CRD_LIBRARY=tools/_variants/libcrd_<name>.so built with
+"""Chunk heights / mappings of the two- (three-: STEPS=3 NSTEPS=96) steps-per-launch kernel, on a TUNING build (CRD_LIBRARY=tools/_variants/libcrd_<name>.so built with
 -DCRD_TUNING_BUILD [-DCRD_PREFETCH_TWO=2] [-DCRD_NO_LOCKSTEP_TWO]).  CASES="precision:cols:nx:ny,..."""
 import os
 import statistics
@@ -17,7 +17,9 @@ for case in os.environ.get("CASES", "f64:1:8192:8192,f32:2:8192:8192").split(","
     dt = 0.8 * crd.stable_dt(p)
     y0 = crd.initial_conditions(crd.run_config(p, wave_length=0.1, wave_width=0.5))
     chunks = [int(v) for v in os.environ.get("CHUNKS", "48,64,96,128,192,256").split(",")]
-    variants = [(steps, chunk, remap) for steps in (1, 2) for chunk in ((32,) if steps == 1 else chunks) for remap in [int(v) for v in os.environ.get("REMAPS", "0,1,2").split(",")]]
+    step_counts = [int(v) for v in os.environ.get("STEPS", "1,2").split(",")]  # (3: the three-step kernel, FHN fp64 one column per lane)
+    nsteps = int(os.environ.get("NSTEPS", "80"))
+    variants = [(steps, chunk, remap) for steps in step_counts for chunk in ((32,) if steps == 1 else chunks) for remap in [int(v) for v in os.environ.get("REMAPS", "0,1,2").split(",")]]
     with crd.Slab(p) as slab:
         slab.upload(y0)
         del y0
@@ -29,7 +31,7 @@ for case in os.environ.get("CASES", "f64:1:8192:8192,f32:2:8192:8192").split(","
                 slab.set_launch_plan(0, 0, int(cols), 1, steps)
                 os.environ["CRD_FUSED_CHUNK"], os.environ["CRD_FUSED_REMAP"] = str(chunk), str(remap)
                 slab.step_rk4(0.0, dt, 8)
-                ms, _, _ = slab.step_rk4_timed(0.0, dt, 80)
-                res[v].append(ms / 80)
+                ms, _, _ = slab.step_rk4_timed(0.0, dt, nsteps)
+                res[v].append(ms / nsteps)
         for v in variants:
             print("%s %s %s cols %s %sx%s steps/launch %d chunk %3d map %d: median %.4f ms/step  min %.4f" % (tag, model, prec, cols, nx, ny, v[0], v[1], v[2], statistics.median(res[v]), min(res[v])), flush=True)
