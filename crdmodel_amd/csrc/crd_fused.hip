@@ -13,7 +13,11 @@ bool fused_two_steps_supported(const SlabDesc &d) { return d.nyl >= 4 * kStepHal
 // kernels do, else one.
 int fused_steps_supported(int precision, const SlabDesc &d, int want)
 {
-	if (want >= 3 && precision == CRD_PRECISION_F64 && kernel_model(d) == CRD_MODEL_FHN && d.wrap && d.nyl >= 6 * kStepHalo) return 3;
+	bool three = precision == CRD_PRECISION_F64 && kernel_model(d) == CRD_MODEL_FHN;
+#ifdef CRD_THREE_STEPS_GOLDBETER
+	three = three || (precision == CRD_PRECISION_F64 && kernel_model(d) == CRD_MODEL_GOLDBETER);
+#endif
+	if (want >= 3 && three && d.wrap && d.nyl >= 6 * kStepHalo) return 3;
 	return (want >= 2 && fused_two_steps_supported(d)) ? 2 : 1;
 }
 

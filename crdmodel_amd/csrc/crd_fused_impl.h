@@ -928,7 +928,12 @@ __device__ __forceinline__ void fused_item_multi_step(const Slab<Real> &s, const
 		// `if (lane_stores)` the compiler puts a skip branch (s_cbranch_execz) in front of the stores, a wavefront without a storing lane
 		// then has fewer operations in flight than the wait assumes, and its ring read can overtake the LDS-DMA fill of its slot.
 		if constexpr (FED >= FILL) {
-#ifndef CRD_PROBE_NOSTORE
+#if defined(CRD_PROBE_BRANCHY_STORES)  // (probe build: round 5's form, stores under the lanes' condition -- what the parked lanes cost; NOT safe, see above)
+			if (lane_stores) {
+				buffer_row_store<NT>(row_resource(out_row_u), xb, nu);
+				buffer_row_store<NT>(row_resource(out_row_v), xb, nv);
+			}
+#elif !defined(CRD_PROBE_NOSTORE)
 			buffer_row_store<NT>(row_resource(out_row_u), xb_store, nu);
 			buffer_row_store<NT>(row_resource(out_row_v), xb_store, nv);
 #else
@@ -1097,8 +1102,13 @@ int resident_wavefronts()
 
 // Three steps per launch (round 6): FHN in fp64, one column per lane, the block as the strip -- the one kernel whose launch is bound by
 // its memory traffic rather than by issue.
+#ifdef CRD_THREE_STEPS_GOLDBETER  // (probe build: the three-step pipeline for Goldbeter too -- profiles/r06/goldbeter_floor.txt)
+template <typename Real, int MODEL>
+constexpr bool kCanThreeSteps = sizeof(Real) == 8 && (MODEL == CRD_MODEL_FHN || MODEL == CRD_MODEL_GOLDBETER);
+#else
 template <typename Real, int MODEL>
 constexpr bool kCanThreeSteps = sizeof(Real) == 8 && MODEL == CRD_MODEL_FHN;
+#endif
 
 template <typename Real, int MODEL>
 int resident_wavefronts(int cols, int steps = 1)
@@ -1354,7 +1364,12 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (with_selects) with_nt(std::true_type{});
 				else with_nt(std::false_type{});
 			};
-			if (steps >= 2 && absorb12) {
+			if (steps == 3 && absorb12) {
+				// Three steps per launch: the kernel with the selects needs 246 registers against 244 -- two wavefronts per SIMD either
+				// way -- so ONE launch of it serves (it decides per chunk which body an item runs); the cut below would only add two
+				// latency-bound band launches (measured: 0.2180 against 0.2048 ms per step with the cut).
+				launch(true);
+			} else if (steps == 2 && absorb12) {
 				// Two steps per launch with absorbing rows on.  The ABSORB kernel holds the body with the selects AND the one without
 				// (it decides per chunk), and the former's scalar registers spill into two vector registers of the whole kernel: 170
 				// VGPRs, two wavefronts per SIMD instead of three for EVERY item of the launch (+20 ... 38 % measured).  So the rows are
@@ -1451,7 +1466,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		// measurement runs (a Goldbeter launch sequence lost 15 % over five candidates timed one after the other), and a
 		// candidate must not win or lose by its place in the queue.
 		constexpr int kCandidates = kNumPlanCandidates, kRounds = 3;
-		const bool two_steps_ok = kCanTwoSteps && !c.embed && c.steps == 1 && d.nyl >= 4 * kStepHalo;  // (the caller steps pairs once the plan says so)
+		// (a candidate that takes more steps per launch than the call reads more rows beyond the launch's: they must exist -- a launch of
+		// a multi-slab cycle that reaches far into the ghost region is measured with the candidates of its own step count only)
+		const bool room_for_two = d.wrap || (row_begin >= -(kGhost - 2 * kStepHalo) && row_end <= d.nyl + (kGhost - 2 * kStepHalo));
+		const bool two_steps_ok = kCanTwoSteps && !c.embed && c.steps == 1 && d.nyl >= 4 * kStepHalo && room_for_two;  // (the caller steps pairs once the plan says so)
 		const bool three_steps_ok = two_steps_ok && kCanThreeSteps<Real, MODEL> && d.nyl >= 6 * kStepHalo && d.wrap;  // (... or triples: single slabs)
 		float t_best[kCandidates];
 		bool live[kCandidates];
@@ -1557,7 +1575,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		const int apron = steps * (c.embed ? kApron + 1 : kApron);
 		g.real_bytes = (int)sizeof(Real);
 		g.model = MODEL;
-		g.absorb = steps >= 2 ? 0 : (absorb1 ? 1 : 0);  // (several steps with absorbing rows on: the bulk goes out as the select-free kernel)
+		g.absorb = steps == 3 ? (absorb12 ? 1 : 0) : steps == 2 ? 0 : (absorb1 ? 1 : 0);  // (two steps with absorbing rows on: the bulk goes out as the select-free kernel)
 		g.embed = c.embed;
 		g.cols = cols;
 		g.nt = nt ? 1 : 0;
