@@ -8,7 +8,8 @@
 //
 // Semantics kept from NCCL: the k-th send from rank a to rank b pairs with the k-th receive at b from a; the operations of a
 // group complete together; an all-reduce is one call per rank in the same order; everything is ordered behind the work already
-// on the stream it is given.  Not kept: asynchrony -- a call returns when its data has moved (the stream is synchronised), so a
+// on the stream it is given; with CRD_STANDIN_SHUFFLE the operations of a group complete in a random order, with random latencies
+// (run_group_shuffled).  Not kept: asynchrony -- a call returns when its data has moved (the stream is synchronised), so a
 // mis-paired protocol shows as a timeout error (CRD_STANDIN_TIMEOUT_S, default 60 s) rather than as a hang.  Sums are taken
 // in rank order (RCCL's ring order differs: states are compared to round-off where a sum over ranks is involved).
 #include <fcntl.h>
@@ -114,11 +115,87 @@ size_t size_of(ncclDataType_t t)
 	}
 }
 
+// CRD_STANDIN_SHUFFLE=seed (round 6): the operations of a group complete in ANY order -- what NCCL promises is only that the k-th send
+// from a to b pairs with the k-th receive at b from a.  The group's operations are queued per (peer, direction), in issue order; the
+// progress loop below picks a queue at random, completes its head if it can go (a free slot for a send, a message there for a receive)
+// and sleeps a random time of up to CRD_STANDIN_LATENCY_US microseconds in front of it.  A protocol that leans on the order in which
+// this stand-in -- or an MPI -- happens to deliver (the reference's Exchange() does at two ranks, where both neighbours are one peer:
+// src/FHNmodel_torus.cpp:805,811) mis-pairs its rows under it; libcrd's halo plan must not.
+ncclResult_t run_group_shuffled(std::vector<Op> &ops, unsigned seed)
+{
+	static thread_local uint64_t state = 0;
+	if (state == 0) state = 0x9e3779b97f4a7c15ull * (uint64_t)(seed + 1) + (uint64_t)getpid();
+	auto rnd = [&]() {  // xorshift64*
+		state ^= state >> 12;
+		state ^= state << 25;
+		state ^= state >> 27;
+		return state * 0x2545f4914f6cdd1dull;
+	};
+	const char *lat = std::getenv("CRD_STANDIN_LATENCY_US");
+	const unsigned max_latency_us = lat ? (unsigned)std::atoi(lat) : 0u;
+	struct Queued {
+		Op op;
+		uint64_t seq;
+	};
+	std::vector<std::vector<Queued>> queues;  // one per (peer, direction), heads first
+	std::vector<int> key;
+	for (const Op &op : ops) {
+		const int k = op.peer * 2 + (op.send ? 1 : 0);
+		size_t q = 0;
+		while (q < key.size() && key[q] != k) q++;
+		if (q == key.size()) {
+			key.push_back(k);
+			queues.emplace_back();
+		}
+		ncclComm *c = op.comm;
+		if (op.send && op.bytes > c->slot) return failed("message larger than a slot (CRD_STANDIN_SLOT_MB)");
+		queues[q].push_back(Queued{op, op.send ? c->n_sent[op.peer]++ : c->n_received[op.peer]++});  // (sequence numbers in ISSUE order)
+	}
+	std::vector<size_t> head(queues.size(), 0);
+	size_t left = ops.size();
+	const auto t0 = std::chrono::steady_clock::now();
+	const double limit = timeout_s();
+	unsigned idle = 0;
+	while (left > 0) {
+		const size_t q = (size_t)(rnd() % queues.size());
+		if (head[q] >= queues[q].size()) continue;
+		const Queued &it = queues[q][head[q]];
+		ncclComm *c = it.op.comm;
+		Channel &ch = it.op.send ? c->sh->channel[c->rank][it.op.peer] : c->sh->channel[it.op.peer][c->rank];
+		const bool ready = it.op.send ? ch.consumed.load(std::memory_order_acquire) + kSlots > it.seq : ch.sent.load(std::memory_order_acquire) > it.seq;
+		if (!ready) {
+			if (++idle > 200) std::this_thread::sleep_for(std::chrono::microseconds(50));
+			if ((idle & 1023u) == 1023u && std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() > limit)
+				return failed(it.op.send ? "timeout: the peer does not receive (send side, shuffled delivery)" : "timeout: the peer does not send (receive side, shuffled delivery)");
+			continue;
+		}
+		idle = 0;
+		if (max_latency_us) std::this_thread::sleep_for(std::chrono::microseconds(rnd() % (max_latency_us + 1)));
+		if (it.op.send) {
+			if (hipMemcpyAsync(c->slot_of(c->rank, it.op.peer, it.seq), it.op.buf, it.op.bytes, hipMemcpyDeviceToHost, it.op.stream) != hipSuccess ||
+			    hipStreamSynchronize(it.op.stream) != hipSuccess)
+				return failed("device-to-host copy failed");
+			ch.bytes[it.seq % kSlots] = it.op.bytes;
+			ch.sent.store(it.seq + 1, std::memory_order_release);
+		} else {
+			if (ch.bytes[it.seq % kSlots] != it.op.bytes) return failed("a receive met a send of another size: the ranks' operations are not paired");
+			if (hipMemcpyAsync(it.op.buf, c->slot_of(it.op.peer, c->rank, it.seq), it.op.bytes, hipMemcpyHostToDevice, it.op.stream) != hipSuccess ||
+			    hipStreamSynchronize(it.op.stream) != hipSuccess)
+				return failed("host-to-device copy failed");
+			ch.consumed.store(it.seq + 1, std::memory_order_release);
+		}
+		head[q]++;
+		left--;
+	}
+	return ncclSuccess;
+}
+
 ncclResult_t run_group(std::vector<Op> &ops)
 {
 	// everything already on the streams first: the data the sends read has been produced
 	for (const Op &op : ops)
 		if (hipStreamSynchronize(op.stream) != hipSuccess) return failed("hipStreamSynchronize failed");
+	if (const char *e = std::getenv("CRD_STANDIN_SHUFFLE")) return run_group_shuffled(ops, (unsigned)std::atoi(e));
 	for (const Op &op : ops) {
 		if (!op.send) continue;
 		ncclComm *c = op.comm;

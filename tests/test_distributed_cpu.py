@@ -383,3 +383,31 @@ def test_ranks_started_by_an_external_launcher_fall_back_too(failure):
     # asked for by name: no fallback, status 4 on every rank
     res = _run_ranks_like_torchrun(2, common + ["--transport", "rccl"], env)
     assert [r[0] for r in res] == [4, 4] and not any(ln.startswith("{") for ln in res[0][1].splitlines())
+
+
+def test_preflight_says_within_a_minute_whether_a_multi_rank_run_would_come_up():
+    """`bench.py --gpus N --preflight` (round 6; the round-5 verdict's item 7): roll call, ring bring-up, communicator self-report and the
+    32-row halo self-check ONLY -- nothing planned, stepped or timed -- and ONE JSON line either way, so that a failing scaling run says
+    why.  Here against the stand-in, self-launched (the form the driver uses) and with ranks started as torch.distributed.run starts them;
+    a ring that does not come up gives {"ok": false, "reasons": [...]} and a non-zero status, never the LOCAL leg."""
+    import time
+
+    common = ["--gpus", "3", "--size", "96", "--preflight", "--crd-module", "tests.standin_crd"]
+    t0 = time.monotonic()
+    r = _run_bench(common)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["preflight"] is True and d["ok"] is True and d["n_gpus"] == 3 and d["halo"]["transport"] == "rccl" and d["halo"]["rccl_comm_count"] == 3
+    assert d["halo"]["halo_selfcheck"]["ok"] and d["halo"]["halo_selfcheck"]["depth"] == 32 and "metric" not in d and "launcher" in d
+    assert time.monotonic() - t0 < 60
+    r = _run_bench(common, extra_env={"STANDIN_FAIL_RING": "1"})
+    assert r.returncode != 0
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert d["preflight"] is True and d["ok"] is False and d["reasons"] and "local" not in json.dumps(d).lower().replace("local_rank", "")
+    # ... and under an external launcher: rank 0 prints the line, every rank leaves with the same status
+    outs = _run_ranks_like_torchrun(2, ["--gpus", "2", "--size", "64", "--preflight", "--crd-module", "tests.standin_crd"], {})
+    assert [o[0] for o in outs] == [0, 0], outs
+    d = json.loads(outs[0][1].strip().splitlines()[-1])
+    assert d["preflight"] and d["ok"] and d["n_gpus"] == 2 and not outs[1][1].strip()

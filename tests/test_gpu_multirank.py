@@ -48,12 +48,14 @@ def unique_id(standin):
     return buf.raw
 
 
-def run_ring(standin, spec, world, tmp_path):
+def run_ring(standin, spec, world, tmp_path, shuffle_seed=None):
     spec_path = tmp_path / "programme.json"
     spec_path.write_text(json.dumps(spec))
     raw_id = unique_id(standin)
     ident = raw_id.hex()
     env = dict(os.environ, CRD_RCCL_LIBRARY=standin, CRD_STANDIN_TIMEOUT_S="40")
+    if shuffle_seed is not None:  # the operations of every ncclGroup complete in a random order, each behind a random latency of up to 300 us
+        env.update(CRD_STANDIN_SHUFFLE=str(shuffle_seed), CRD_STANDIN_LATENCY_US="300")
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ring_rank_worker.py"), str(r), str(world), ident, str(spec_path), str(tmp_path / ("rank%d.npz" % r))],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = []
@@ -93,11 +95,15 @@ def plans(world, *per_rank):
     return [list(per_rank[k % len(per_rank)]) for k in range(world + 1)]
 
 
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_fixed_steps_on_a_ring_of_processes(gpu_device, standin, tmp_path, world):
+@pytest.mark.parametrize("world,shuffle_seed", [(2, None), (3, None), (4, None), (2, 6), (5, 11)], ids=["2", "3", "4", "2-shuffled", "5-shuffled"])
+def test_fixed_steps_on_a_ring_of_processes(gpu_device, standin, tmp_path, world, shuffle_seed):
     """Exchange cycles carried across calls, periods 5 / 8 / 16, halo slack 2, launch plans that pair steps on some ranks only,
     absorbing rows on rank 0 / the last rank (tBoundary inside the run), a one-rank upload in mid-cycle (the ring then agrees to
-    start a fresh cycle), staged <-> one-launch stepper switches: the ring's rows == the single slab's, bit for bit."""
+    start a fresh cycle), staged <-> one-launch stepper switches: the ring's rows == the single slab's, bit for bit.
+    "shuffled" (round 6): the transport completes the operations of every ncclGroup in a random order behind random latencies
+    (tests/native/ring_standin_rccl.cpp: run_group_shuffled) -- at two ranks both neighbours are ONE peer and the two rows a rank sends it
+    are told apart by nothing but their order of issue (crd_halo_plan), the case the reference's Exchange() leaves to MPI's message
+    ordering (src/FHNmodel_torus.cpp:805,811); five ranks are the most this box's six-process limit on the GPU allows."""
     ny = world * 131 + (world - 1)  # slabs of unequal height, every one above the 64 ghost rows of period 16 and above 4 bands of 32
     spec = dict(model="fhn", surface="torus", nx=200, ny=ny, precision="f64", t_boundary=0.0, dt_factor=0.7, vary_beta=1)
     dt = spec["dt_factor"] * crd.stable_dt(worker.problem(crd, spec))
@@ -111,7 +117,7 @@ def test_fixed_steps_on_a_ring_of_processes(gpu_device, standin, tmp_path, world
         ["stepper", "staged"], ["step", 3], ["stepper", "fused"], ["step", 6], ["snapshot"],
         ["period", 16], ["plan", plans(world, one_step, two_steps)], ["step", 35], ["scale_rows_of", 0, 0.9990234375], ["step", 2],
     ]
-    ring, _ = run_ring(standin, spec, world, tmp_path)
+    ring, _ = run_ring(standin, spec, world, tmp_path, shuffle_seed)
     single, _ = run_single(spec, world)
     assert len(ring) == len(single) == 7
     for k, (a, b) in enumerate(zip(ring, single)):
