@@ -1364,12 +1364,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 				if (with_selects) with_nt(std::true_type{});
 				else with_nt(std::false_type{});
 			};
-			if (steps == 3 && absorb12) {
-				// Three steps per launch: the kernel with the selects needs 246 registers against 244 -- two wavefronts per SIMD either
-				// way -- so ONE launch of it serves (it decides per chunk which body an item runs); the cut below would only add two
-				// latency-bound band launches (measured: 0.2180 against 0.2048 ms per step with the cut).
-				launch(true);
-			} else if (steps == 2 && absorb12) {
+			if (steps >= 2 && absorb12) {
+				// (Three steps per launch alike: ONE launch of the kernel with the selects -- 246 registers against 244, two wavefronts per
+				// SIMD either way -- measured 0.2579 ms per step against 0.2180 with the cut and 0.2049 without absorbing rows: it is
+				// the kernel that holds both bodies that is slow, not its occupancy.)
 				// Two steps per launch with absorbing rows on.  The ABSORB kernel holds the body with the selects AND the one without
 				// (it decides per chunk), and the former's scalar registers spill into two vector registers of the whole kernel: 170
 				// VGPRs, two wavefronts per SIMD instead of three for EVERY item of the launch (+20 ... 38 % measured).  So the rows are
@@ -1575,7 +1573,7 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		const int apron = steps * (c.embed ? kApron + 1 : kApron);
 		g.real_bytes = (int)sizeof(Real);
 		g.model = MODEL;
-		g.absorb = steps == 3 ? (absorb12 ? 1 : 0) : steps == 2 ? 0 : (absorb1 ? 1 : 0);  // (two steps with absorbing rows on: the bulk goes out as the select-free kernel)
+		g.absorb = steps >= 2 ? 0 : (absorb1 ? 1 : 0);  // (several steps with absorbing rows on: the bulk goes out as the select-free kernel)
 		g.embed = c.embed;
 		g.cols = cols;
 		g.nt = nt ? 1 : 0;

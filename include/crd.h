@@ -450,8 +450,10 @@ typedef struct crd_launch_plan {
 	                           * arithmetic in fp32 */
 	int32_t nontemporal_stores; /* 1: the new state is written with the non-temporal hint (it is not read again by the launch, and
 	                             * does not displace from L2 what neighbouring work items share) */
-	int32_t steps_per_launch; /* 1; 2: one launch advances the state by TWO RK4 steps (single slabs: the state crosses memory once per two
-	                           * steps, for twice the pipeline registers and a 16-row / 16-column apron); crd_step_rk4 then issues pairs */
+	int32_t steps_per_launch; /* 1; 2: one launch advances the state by TWO RK4 steps (the state crosses memory once per two steps, for twice
+	                           * the pipeline registers and a 16-row / 16-column apron); crd_step_rk4 then issues pairs; 3 (FHN fp64 on a
+	                           * single slab; elsewhere taken as 2): THREE steps, a block's wavefronts running as one strip; triples, then
+	                           * a pair or a single step for what is left.  What crd_get_launch_plan reports is what a launch does. */
 	double ms_default, ms_chosen; /* measured times PER STEP: plain plan, chosen plan */
 } crd_launch_plan;
 int crd_set_autotune(crd_ctx *ctx, int on);
@@ -484,7 +486,7 @@ int crd_get_launch_geometry(crd_ctx *ctx, crd_launch_geometry *out);
  * columns_per_lane, nontemporal_stores and steps_per_launch of *out are set, the rest zero.  (tools/plan_sweep.py profiles every one of them;
  * tests/test_profiles.py checks that profiles/pmc_traffic.json has an entry for each.) */
 int crd_launch_plan_candidate(int index, crd_launch_plan *out);
-/* Use THIS plan (chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1, steps per launch 1..2) for the fixed-step kernel instead of measuring one -- a plan
+/* Use THIS plan (chunk mode 0..2, mapping 0..2, columns per lane 1..2, non-temporal stores 0..1, steps per launch 1..3) for the fixed-step kernel instead of measuring one -- a plan
  * read back from an earlier context of the same shape on the same device (the measurement costs ~0.45 s per context at 8192^2), or
  * a profiling run in which every launch of the kernel should be the plan a previous run chose (`bench.py --launch-plan`).  A pinned
  * plan applies to launches of EVERY size (a measured one only to launches of the height it was measured on).  Where a choice cannot
