@@ -730,6 +730,8 @@ int crd_get_launch_plan(const crd_ctx *c, crd_launch_plan *out)
 	out->columns_per_lane = c->plan.tuned ? c->plan.cols : fused_default_columns(c->p.precision, c->nx);
 	out->nontemporal_stores = c->plan.nt;
 	out->steps_per_launch = c->plan.tuned ? fused_steps_supported(c->p.precision, c->desc, c->plan.steps) : 1;
+	// (the three-step pipeline has ONE form per precision -- one column per lane in fp64, two in fp32 --, whatever the plan's columns say)
+	if (out->steps_per_launch == 3) out->columns_per_lane = c->p.precision == CRD_PRECISION_F64 ? 1 : 2;
 	out->ms_default = c->plan.ms_default;
 	out->ms_chosen = c->plan.ms_best;
 	return CRD_OK;
@@ -754,6 +756,8 @@ int crd_get_launch_geometry(crd_ctx *c, crd_launch_geometry *out)
 		call.absorb[4] = call.absorb[3];
 	}
 	call.steps = c->plan.tuned ? fused_steps_supported(c->p.precision, c->desc, c->plan.steps) : 1;
+	// (fp32 triples any stage of which has the absorbing rows on are stepped as a pair and a single step: run_steps, triple_absorbs)
+	if (call.steps == 3 && c->p.precision != CRD_PRECISION_F64 && (call.absorb[0] || call.absorb[1] || call.absorb[2] || call.absorb[3])) call.steps = 2;
 	call.plan = &c->plan;
 	call.geometry = &g;
 	HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, -ext, c->nyl + ext, 0, 0, c->compute));

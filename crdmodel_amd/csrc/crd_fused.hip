@@ -8,12 +8,13 @@ bool fused_step_supported(int, const SlabDesc &d) { return d.nyl >= 2 * kStepHal
 
 bool fused_two_steps_supported(const SlabDesc &d) { return d.nyl >= 4 * kStepHalo && kernel_model(d) != kModelDiffusionOnly; }
 
-// Steps one launch of this slab takes when the plan asks for `want` (1 .. 3): three only where the three-step kernel exists (FHN, fp64:
+// Steps one launch of this slab takes when the plan asks for `want` (1 .. 3): three only where the three-step kernel exists (FHN:
 // kCanThreeSteps) and on a single slab (rows wrap; the exchange cycles of multi-slab runs step pairs), else two where the two-step
 // kernels do, else one.
 int fused_steps_supported(int precision, const SlabDesc &d, int want)
 {
-	bool three = precision == CRD_PRECISION_F64 && kernel_model(d) == CRD_MODEL_FHN;
+	// (FHN: fp64 with one column per lane, fp32 with two -- an even nx; crd_fused_impl.h: kThreeStepCols)
+	bool three = kernel_model(d) == CRD_MODEL_FHN && (precision == CRD_PRECISION_F64 || d.nx % 2 == 0);
 #ifdef CRD_THREE_STEPS_GOLDBETER
 	three = three || (precision == CRD_PRECISION_F64 && kernel_model(d) == CRD_MODEL_GOLDBETER);
 #endif

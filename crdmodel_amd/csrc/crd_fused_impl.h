@@ -1100,21 +1100,25 @@ int resident_wavefronts()
 	return slots;
 }
 
-// Three steps per launch (round 6): FHN in fp64, one column per lane, the block as the strip -- the one kernel whose launch is bound by
-// its memory traffic rather than by issue.
-#ifdef CRD_THREE_STEPS_GOLDBETER  // (probe build: the three-step pipeline for Goldbeter too -- profiles/r06/goldbeter_floor.txt)
+// Three steps per launch (round 6), for the kernels whose two-step launch is bound by its memory path rather than by issue (DESIGN.md
+// 4c, 4d): FHN in fp64 with one column per lane and the block as the strip (232 valid lanes of 256), and FHN in fp32 with two columns
+// per lane and a strip per wavefront (104 valid columns of 128 -- no exchange between wavefronts).  kThreeStepCols: the columns per
+// lane of the model's three-step kernel, 0 where there is none.
+#ifdef CRD_THREE_STEPS_GOLDBETER  // (probe build: the three-step pipeline for Goldbeter fp64 too -- profiles/r06/goldbeter_floor.txt)
 template <typename Real, int MODEL>
-constexpr bool kCanThreeSteps = sizeof(Real) == 8 && (MODEL == CRD_MODEL_FHN || MODEL == CRD_MODEL_GOLDBETER);
+constexpr int kThreeStepCols = (MODEL == CRD_MODEL_FHN || (MODEL == CRD_MODEL_GOLDBETER && sizeof(Real) == 8)) ? (sizeof(Real) == 8 ? 1 : 2) : 0;
 #else
 template <typename Real, int MODEL>
-constexpr bool kCanThreeSteps = sizeof(Real) == 8 && MODEL == CRD_MODEL_FHN;
+constexpr int kThreeStepCols = MODEL == CRD_MODEL_FHN ? (sizeof(Real) == 8 ? 1 : 2) : 0;
 #endif
+template <typename Real, int MODEL>
+constexpr bool kCanThreeSteps = kThreeStepCols<Real, MODEL> != 0;
 
 template <typename Real, int MODEL>
 int resident_wavefronts(int cols, int steps = 1)
 {
 	if constexpr (kCanThreeSteps<Real, MODEL>)
-		if (steps == 3) return resident_wavefronts<Real, MODEL, 1, 3>();
+		if (steps == 3) return resident_wavefronts<Real, MODEL, kThreeStepCols<Real, MODEL>, 3>();
 	if constexpr (MODEL != kModelDiffusionOnly)  // (the diffusion-only variant has no two-step instantiation)
 		if (steps == 2) return cols == 2 ? resident_wavefronts<Real, MODEL, 2, 2>() : resident_wavefronts<Real, MODEL, 1, 2>();
 	return cols == 2 ? resident_wavefronts<Real, MODEL, 2, 1>() : resident_wavefronts<Real, MODEL, 1, 1>();
@@ -1197,7 +1201,9 @@ constexpr PlanCandidate kPlanCandidates[] = {
     // sixth (round 6): three steps per launch, the block as the strip (FHN fp64: kCanThreeSteps), non-temporal stores
     // (whole-rounds chunks win by 7 % -- 293 rows = two rounds of resident blocks on 8192^2 against 192 rows = three and a bit --, plain
     // stores by half a per cent on some boxes)
-    {0, 0, 1, 1, 3}, {0, 1, 1, 1, 3}, {0, 2, 1, 1, 3}, {1, 0, 1, 1, 3}, {1, 1, 1, 1, 3}, {1, 0, 1, 0, 3}, {1, 1, 1, 0, 3}};
+    {0, 0, 1, 1, 3}, {0, 1, 1, 1, 3}, {0, 2, 1, 1, 3}, {1, 0, 1, 1, 3}, {1, 1, 1, 1, 3}, {1, 0, 1, 0, 3}, {1, 1, 1, 0, 3},
+    // ... and in fp32: two columns per lane, a strip per wavefront (kThreeStepCols)
+    {0, 0, 2, 1, 3}, {0, 1, 2, 1, 3}, {0, 2, 2, 1, 3}, {1, 0, 2, 1, 3}, {1, 1, 2, 1, 3}, {2, 1, 2, 1, 3}};
 constexpr int kNumPlanCandidates = (int)(sizeof kPlanCandidates / sizeof kPlanCandidates[0]);
 
 template <typename Real, int MODEL>
@@ -1218,7 +1224,8 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	if (row_end2 < row_begin2) row_end2 = row_begin2;
 	// Two steps per launch: plain steps only, and not the diffusion-only variant (no instantiation: that model is a plumbing case).
 	constexpr bool kCanTwoSteps = MODEL != kModelDiffusionOnly;
-	if (c.steps != 1 && (c.embed || !((c.steps == 2 && kCanTwoSteps) || (c.steps == 3 && kCanThreeSteps<Real, MODEL>)))) return hipErrorInvalidValue;
+	if (c.steps != 1 && (c.embed || !((c.steps == 2 && kCanTwoSteps) || (c.steps == 3 && kCanThreeSteps<Real, MODEL> && (kThreeStepCols<Real, MODEL> == 1 || d.nx % 2 == 0)))))
+		return hipErrorInvalidValue;
 	// rows may extend into the ghost region (deep-halo steps), but the pipeline reads kStepHalo rows per step beyond them
 	if (!d.wrap && (row_begin < -(kGhost - c.steps * kStepHalo) || row_end > d.nyl + (kGhost - c.steps * kStepHalo))) return hipErrorInvalidValue;
 	const Slab<Real> s = typed<Real>(d);
@@ -1261,6 +1268,9 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 	const bool absorb1 = kCanAbsorb && (c.absorb[0] || c.absorb[1] || c.absorb[2] || c.absorb[3] || (c.embed && c.absorb[4]));
 	const bool absorb12 = absorb1 || (kCanAbsorb && (c.absorb2[0] || c.absorb2[1] || c.absorb2[2] || c.absorb2[3])) ||
 	                      (kCanAbsorb && c.steps == 3 && (c.absorb3[0] || c.absorb3[1] || c.absorb3[2] || c.absorb3[3]));  // (any stage of any step of the launch)
+	// (fp32: the three-step pipeline with the absorbing-row selects does not fit the registers -- 256 and scratch; the steppers step
+	// such triples as a pair and a single step, run_steps: triple_absorbs)
+	if (c.steps == 3 && sizeof(Real) == 4 && absorb12) return hipErrorInvalidValue;
 	const dim3 block(kLanes * sw);
 
 	int cols = cols_default, steps = 1;
@@ -1296,12 +1306,12 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		}
 	};
 	auto configure = [&](int one_round, int remap, int want_cols, int want_nt = 0, int want_steps = 1) {
-		steps = (want_steps == 3 && kCanThreeSteps<Real, MODEL>) ? 3 : (want_steps >= 2 && kCanTwoSteps) ? 2 : 1;
+		steps = (want_steps == 3 && kCanThreeSteps<Real, MODEL> && (kThreeStepCols<Real, MODEL> == 1 || cols2_ok)) ? 3 : (want_steps >= 2 && kCanTwoSteps) ? 2 : 1;
 		nt = want_nt != 0;
 		if (const char *e = tuning::knob("CRD_FUSED_NT")) nt = std::atoi(e) != 0;
 		cols = (want_cols == 2 && cols2_ok) ? 2 : 1;
 		if (const char *e = tuning::knob("CRD_FUSED_COLS")) cols = (std::atoi(e) == 2 && cols2_ok) ? 2 : 1;
-		if (steps == 3) cols = 1;  // (the three-step pipeline: one column per lane)
+		if (steps == 3) cols = kThreeStepCols<Real, MODEL>;  // (the three-step pipeline has ONE form per model and precision)
 		const int valid = cols * kLanes - 2 * steps * (c.embed ? kApron + 1 : kApron);  // (the embedded estimators' fifth stage costs one more apron column per side)
 		a.nstrips = (d.nx + valid - 1) / valid;
 		if ((steps == 2 && cols == 1 && kCoop<Real, MODEL, 1, 2>) || (steps == 3 && kCoop<Real, MODEL, 1, 3>)) {  // the block as the strip: one apron around its sw wavefronts
@@ -1341,7 +1351,9 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 			auto with = [&](auto absorb_c, auto cols_c, auto nt_c, auto steps_c) {
 				constexpr int kSteps = decltype(steps_c)::value;
 				auto kernel = crd_rk4_fused_step_kernel<Real, MODEL, decltype(absorb_c)::value && kCanAbsorb, 0, decltype(cols_c)::value, decltype(nt_c)::value,
-				                                        (kSteps == 3 ? kCanThreeSteps<Real, MODEL> && decltype(cols_c)::value == 1 : kCanTwoSteps) ? kSteps : 1>;
+				                                        (kSteps == 3 ? kCanThreeSteps<Real, MODEL> && decltype(cols_c)::value == kThreeStepCols<Real, MODEL> &&
+				                                                           !(sizeof(Real) == 4 && decltype(absorb_c)::value)  // (never launched: see above)
+				                                                     : kCanTwoSteps) ? kSteps : 1>;
 				hipEvent_t e0 = first_launch ? c.start_event : nullptr, e1 = last_launch ? c.done_event : nullptr;
 				if (e0 || e1) hipExtLaunchKernelGGL(kernel, dim3(a.nblocks), block, 0, st, e0, e1, 0, s, a);
 				else kernel<<<a.nblocks, block, 0, st>>>(s, a);
@@ -1468,7 +1480,8 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		// a multi-slab cycle that reaches far into the ghost region is measured with the candidates of its own step count only)
 		const bool room_for_two = d.wrap || (row_begin >= -(kGhost - 2 * kStepHalo) && row_end <= d.nyl + (kGhost - 2 * kStepHalo));
 		const bool two_steps_ok = kCanTwoSteps && !c.embed && c.steps == 1 && d.nyl >= 4 * kStepHalo && room_for_two;  // (the caller steps pairs once the plan says so)
-		const bool three_steps_ok = two_steps_ok && kCanThreeSteps<Real, MODEL> && d.nyl >= 6 * kStepHalo && d.wrap;  // (... or triples: single slabs)
+		const bool three_steps_ok = two_steps_ok && kCanThreeSteps<Real, MODEL> && (kThreeStepCols<Real, MODEL> == 1 || cols2_ok) && d.nyl >= 6 * kStepHalo && d.wrap &&
+		                            !(sizeof(Real) == 4 && absorb12);  // (... or triples: single slabs; fp32 without absorbing rows on)
 		float t_best[kCandidates];
 		bool live[kCandidates];
 		int reps = 3;

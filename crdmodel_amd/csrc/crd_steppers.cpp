@@ -239,6 +239,16 @@ bool pair_is_exact(const crd_ctx *c, double t0, int64_t s, double dt)
 		if (absorbing(c, t2 + cs4[k] * dt) != absorbing(c, (t + dt) + cs4[k] * dt)) return false;
 	return true;
 }
+// Does any stage of the three steps from t on have the absorbing rows on?  (The fp32 three-step kernel has no instantiation with the
+// selects -- it would not fit the registers: 256 + scratch --; such triples are stepped as a pair and a single step.)
+bool triple_absorbs(const crd_ctx *c, double t, double dt)
+{
+	const double ts[3] = {t, t + dt, (t + dt) + dt}, cs4[4] = {0.0, 0.5, 0.5, 1.0};
+	for (double tk : ts)
+		for (int k = 0; k < 4; k++)
+			if (absorbing(c, tk + cs4[k] * dt)) return true;
+	return false;
+}
 // ... and steps s, s + 1, s + 2 as one three-step launch: the third step's flags come from (t + dt) + dt.
 bool triple_is_exact(const crd_ctx *c, double t0, int64_t s, double dt)
 {
@@ -358,12 +368,14 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			const int per_launch = (stepper == CRD_STEPPER_FUSED && c->plan.tuned) ? fused_steps_supported(c->p.precision, c->desc, c->plan.steps) : 1;
 			const bool pairing = per_launch >= 2;
 			// (a three-step plan: triples while three steps are left, then a pair or a single step)
-			int rc, took = (per_launch == 3 && s + 3 <= nsteps && triple_is_exact(c, t0, s, dt)) ? 3 : (pairing && s + 2 <= nsteps && pair_is_exact(c, t0, s, dt)) ? 2 : 1;
+			const bool triple = per_launch == 3 && s + 3 <= nsteps && triple_is_exact(c, t0, s, dt) && (c->p.precision == CRD_PRECISION_F64 || !triple_absorbs(c, t, dt));
+			int rc, took = triple ? 3 : (pairing && s + 2 <= nsteps && pair_is_exact(c, t0, s, dt)) ? 2 : 1;
 			// every fourth step at most: an event pair around EVERY launch of a short run would sit inside the region being timed.  Only
 			// launches of the plan's own kind are timed (a pairing plan's odd last step, or a pair stepped singly, goes out as a one-step
 			// launch: another kernel, which must not enter the average; runs too short to hold a pair time what there is).
 			const int64_t want = std::min<int64_t>(kMaxTimedLaunches, std::max<int64_t>(1, nsteps / 4));
-			const int kind = (per_launch == 3 && nsteps >= 3) ? 3 : (pairing && nsteps >= 2) ? 2 : 1;
+			const bool triples_here = per_launch == 3 && nsteps >= 3 && (c->p.precision == CRD_PRECISION_F64 || !triple_absorbs(c, t0, dt));  // (the kind of launch the call starts with)
+			const int kind = triples_here ? 3 : (pairing && nsteps >= 2) ? 2 : 1;
 			if (timed_launches && timed < want && took == kind && (s * want / std::max<int64_t>(nsteps, 1)) >= timed && ((s % 4) >= 1 || nsteps < 4)) {
 				kb = &c->ev_k[(size_t)(2 * timed)];
 				ke = &c->ev_k[(size_t)(2 * timed + 1)];

@@ -21,8 +21,8 @@ def test_every_plan_candidate_has_a_pmc_traffic_entry_and_a_kernel_trace_record(
     # the headline workload (BASELINE.json: FHN 8192^2 fp64) and the other two kernels BASELINE's configurations run (C4 Goldbeter fp64, C5 FHN fp32)
     for model, precision in (("fhn", "f64"), ("goldbeter", "f64"), ("fhn", "f32")):
         for plan in plans:
-            if plan[4] == 3 and (model, precision) != ("fhn", "f64"):
-                continue  # (the three-step kernel is FHN fp64's: elsewhere such a plan steps pairs and reports the two-step key)
+            if plan[4] == 3 and (model != "fhn" or plan[2] != (1 if precision == "f64" else 2)):
+                continue  # (the three-step kernels: FHN, one column per lane in fp64, two in fp32; elsewhere such a plan steps pairs and reports the two-step key)
             key = crd.plan_key(model, precision, plan)
             assert key in traffic, "no rocprofv3 --pmc passes recorded for %s (tools/jobs/r06_sweep.sh)" % key
             rec = traffic[key]
@@ -56,9 +56,9 @@ def test_profile_records_of_the_headline_plans_describe_the_kernels_of_this_buil
     models = {"fhn": 0, "goldbeter": 1}
     for model, precision in (("fhn", "f64"), ("goldbeter", "f64"), ("fhn", "f32")):
         for plan in crd.launch_plan_candidates():
-            if plan[4] == 3 and (model, precision) != ("fhn", "f64"):
+            if plan[4] == 3 and (model != "fhn" or plan[2] != (1 if precision == "f64" else 2)):
                 continue
-            cols = plan[2] if plan[4] != 3 else 1
+            cols = plan[2]
             want = crd.kernel_digest_of_table_row(rows[(precision, models[model], 0, 0, cols, plan[3], plan[4])])
             key = crd.plan_key(model, precision, plan)
             assert traffic[key].get("kernel_digest") == want, (key, traffic[key].get("kernel_digest"), want)
@@ -90,6 +90,8 @@ def test_pinned_bench_stats_reproduce_the_sweep_for_the_headline_workload():
 
     stats = _table("plan_stats.json")
     for plan in crd.launch_plan_candidates():
+        if plan[4] == 3 and plan[2] != 1:
+            continue  # (fp32's three-step plans: two columns per lane)
         rec = stats[crd.plan_key("fhn", "f64", plan)]
         if "bench_stats_avg_us" not in rec:
             pytest.fail("no pinned bench.py --stats record for %s (tools/jobs/r06_plan_stats.sh)" % crd.plan_key("fhn", "f64", plan))

@@ -19,8 +19,7 @@ with open(rows_path, "w") as rows:
     plans = crd.launch_plan_candidates()
     if os.environ.get("PLANS"):  # "mode,mapping,cols,nt,steps;...": only these
         plans = [tuple(int(v) for v in q.split(",")) for q in os.environ["PLANS"].split(";") if q]
-    if not (model == "fhn" and prec == "f64"):
-        plans = [q for q in plans if q[4] != 3]
+    plans = [q for q in plans if q[4] != 3 or (model == "fhn" and q[2] == (1 if prec == "f64" else 2))]
     for plan in plans:
         key = crd.plan_key(model, prec, plan)
         d = "/tmp/ps_run"

@@ -113,17 +113,24 @@ def parse(text):
             back = [k for k in range(k0, len(body)) if re.match(r"\s*s_c?branch\w*\s+" + re.escape(label) + r"\s*$", body[k])]
             if not back:
                 continue
-            mix = {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0}
+            mix = {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0, "moves": 0, "nops": 0}
             for ln in body[k0:back[-1] + 1]:
                 ln = ln.strip()
                 if not ln or ln.startswith((";", ".")) or ln.endswith(":"):
                     continue
-                mix[classify(ln.split()[0])] += 1
-            mix["total"] = sum(mix.values())
+                op = ln.split()[0]
+                mix[classify(op)] += 1
+                # plain register moves (not the DPP lane shifts): what the three-address stage updates and the vector-register
+                # constant keep out of the loop (crd_fused_impl.h: stage_fma; crd_device.h: in_vector_registers) -- tests watch the count
+                if op.startswith("v_mov_b") and "dpp" not in ln and "row_" not in ln and "wave_sh" not in ln:
+                    mix["moves"] += 1
+                if op == "s_nop":
+                    mix["nops"] += 1
+            mix["total"] = sum(v for k_, v in mix.items() if k_ not in ("moves", "nops"))
             if best is None or mix["valu"] > best["valu"]:
                 best = mix
         kernels.append({"mangled": name, "exec_skipped_vmem": len(exec_skipped_vmem(body)), "vgprs": meta.get("NumVgprs", 0), "sgprs": meta.get("TotalNumSgprs", meta.get("NumSgprs", 0)), "scratch": meta.get("ScratchSize", 0),
-                        "occupancy": meta.get("Occupancy", 0), "lds": meta.get("LDSByteSize", 0), "loop": best or {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0, "total": 0}})
+                        "occupancy": meta.get("Occupancy", 0), "lds": meta.get("LDSByteSize", 0), "loop": best or {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0, "moves": 0, "nops": 0, "total": 0}})
     for k, nm in zip(kernels, demangle([k["mangled"] for k in kernels])):
         k["name"] = nm
     return kernels

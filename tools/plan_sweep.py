@@ -35,8 +35,8 @@ def main():
     dt = 0.8 * crd.stable_dt(p)
     y0 = crd.initial_conditions(crd.run_config(p, wave_length=0.1, wave_width=0.5, wave_inside=0))
     plans = crd.launch_plan_candidates()
-    if not (a.model == "fhn" and a.precision == "f64"):
-        plans = [q for q in plans if q[4] != 3]  # (the three-step kernel: FHN fp64 only; elsewhere such a plan steps pairs)
+    # (the three-step kernels: FHN, one column per lane in fp64, two in fp32; elsewhere such a plan steps pairs)
+    plans = [q for q in plans if q[4] != 3 or (a.model == "fhn" and q[2] == (1 if a.precision == "f64" else 2))]
     if a.plans:
         plans = [tuple(int(v) for v in q.split(",")) for q in a.plans.split(";") if q]
     recs = []
