@@ -159,18 +159,20 @@ inline int kernel_model(const SlabDesc &d) { return (d.model == CRD_MODEL_GOLDBE
 // field still diffuses to exactly zero (gE = gW = 0, d2y = 0).  The reaction terms ride the same chain: FHN's "- v" is the
 // chain's first addend, 3 u - u^3 = u (3 - u^2) is two multiply-adds, EPSILON (u + b) one with EPSILON b(j) as the row parameter:
 // 9 arithmetic instructions per FHN point (round 4: 15), Goldbeter 25 (31) -- these kernels are bound by vector issue.
-template <typename V, int MODEL>
-__device__ __forceinline__ void rhs_point(V uC, V gW, V gE, V uS, V uN, V v, V cE, V cWn, V cP, typename ScalarOf<V>::type rowp,
-                                          typename ScalarOf<V>::type ka4, bool zero, V &du, V &dv)
+// `west(X)` = fmadd(cWn, gW, X), the western difference's term, LAST in the diffusion's chain: how it is formed is the caller's
+// (rhs_point below: from gW as a value; the packed fp32 marching kernels: without ever assembling gW, crd_fused_impl.h: rhs_lane).
+template <typename V, int MODEL, typename West>
+__device__ __forceinline__ void rhs_point_west(V uC, V gE, V uS, V uN, V v, V cE, V cP, typename ScalarOf<V>::type rowp,
+                                               typename ScalarOf<V>::type ka4, bool zero, V &du, V &dv, West &&west)
 {
 	// the phi second difference as the reference writes it, (uN - 2 uC + uS)
 	const V d2y = fmadd(splat<V>(-2.0), uC, uN) + uS;
 	if (MODEL == kModelDiffusionOnly) {
-		du = fmadd(cWn, gW, fmadd(cE, gE, cP * d2y));
+		du = west(fmadd(cE, gE, cP * d2y));
 		dv = splat<V>(0.0);
 		return;
 	} else if (MODEL == CRD_MODEL_FHN) {
-		const V r = fmadd(cWn, gW, fmadd(cE, gE, fmadd(cP, d2y, -v)));  // diffusion - v
+		const V r = west(fmadd(cE, gE, fmadd(cP, d2y, -v)));  // diffusion - v
 		du = fmadd(uC, fmadd(-uC, uC, splat<V>(3.0)), r);               // + u (3 - u^2)
 		dv = fmadd(in_vector_registers(splat<V>(kFhnEpsilon)), uC, (V)rowp);  // rowp = EPSILON b
 	} else {
@@ -184,12 +186,18 @@ __device__ __forceinline__ void rhs_point(V uC, V gW, V gE, V uS, V uN, V v, V c
 		const V w = fmadd(splat<V>(kGbVm2), z2 * dB, -((y2 * z4) * dA)) * reciprocal(dA * dB);
 		dv = fmadd(splat<V>(-kGbKf), v, w);
 		const V r = fmadd(splat<V>(-kGbK), uC, (V)rowp - dv);  // rowp = v0 + v1 b
-		du = fmadd(cWn, gW, fmadd(cE, gE, fmadd(cP, d2y, r)));
+		du = west(fmadd(cE, gE, fmadd(cP, d2y, r)));
 	}
 	if (zero) {
 		du = splat<V>(0.0);
 		dv = splat<V>(0.0);
 	}
+}
+template <typename V, int MODEL>
+__device__ __forceinline__ void rhs_point(V uC, V gW, V gE, V uS, V uN, V v, V cE, V cWn, V cP, typename ScalarOf<V>::type rowp,
+                                          typename ScalarOf<V>::type ka4, bool zero, V &du, V &dv)
+{
+	rhs_point_west<V, MODEL>(uC, gE, uS, uN, v, cE, cP, rowp, ka4, zero, du, dv, [&](V X) { return fmadd(cWn, gW, X); });
 }
 
 // ... from the neighbour VALUES (the tiled kernels, which have them in LDS): the same differences, the same bits.

@@ -112,6 +112,25 @@ template <typename V, int MODEL>
 __device__ __forceinline__ void rhs_lane(V uC, V uS, V uN, V v, V cE, V cWn, V cP, typename ScalarOf<V>::type rowp, typename ScalarOf<V>::type ka4, bool zero,
                                          V &du, V &dv)
 {
+#ifndef CRD_NO_PAIR_SHIFTS_FOLDED  // (experiment switch)
+	if constexpr (std::is_same<V, float2v>::value) {
+		// Packed fp32, two columns (x, y) per lane (round 6): the shifted PAIRS are never assembled.  pair_from_above / pair_from_below cost a
+		// DPP move AND a plain move each (the packed instructions want both halves in one register pair): 100 plain moves per trip of the
+		// three-step kernel's 797 vector instructions.  Written per column, the lane shift folds into the instruction that consumes it
+		// (VOP2 with a DPP operand): gE.y = shl(u.x) - u.y is one v_sub_f32_dpp, the western term of column x one v_fmac_f32_dpp on gE.y
+		// of the lane below, that of column y a plain multiply-add on gE.x.  Same operations on the same operands: same bits.
+		V gE;
+		gE.x = uC.y - uC.x;
+		gE.y = from_lane_above(uC.x) - uC.y;
+		rhs_point_west<V, MODEL>(uC, gE, uS, uN, v, cE, cP, rowp, ka4, zero, du, dv, [&](V X) {
+			V r;
+			r.x = fmadd(cWn.x, from_lane_below(gE.y), X.x);
+			r.y = fmadd(cWn.y, gE.x, X.y);
+			return r;
+		});
+		return;
+	}
+#endif
 	const V gE = from_lane_above(uC) - uC;
 	rhs_point<V, MODEL>(uC, from_lane_below(gE), gE, uS, uN, v, cE, cWn, cP, rowp, ka4, zero, du, dv);
 }
