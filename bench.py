@@ -615,10 +615,14 @@ def run(args, crd, world, rank, local_rank, device_sync, emit, t_start=None):
             period = {"steps": args.exchange_period, "chosen_by": "--exchange-period"}
         elif min(crd.slab_extents(slab.grid.ny, k, world)[1] - crd.slab_extents(slab.grid.ny, k, world)[0] + 1 for k in range(world)) >= 256:
             trial = {}
-            for e in (8, 10, 16):
+            # (a plan that steps triples inside the cycles -- fp32 -- wants a period it divides: 8 = 3 + 3 + 2 and 10 = 3 + 3 + 3 + 1 end on
+            # another kernel; measured on a rank's 16384 x 2048 share: 9 and 12 steps 58.9 / 59.0 us, 8 / 10 / 16 64.0 / 63.4 / 61.3)
+            triples = ctl.sum_ints([int(slab.launch_plan().get("steps_per_launch", 1) == 3)])[0] == world
+            periods, span = ((8, 9, 12, 16), 144) if triples else ((8, 10, 16), 80)  # (span: whole cycles of each)
+            for e in periods:
                 slab.set_exchange_period(e)
                 slab.step_rk4_timed(0.0, dt, 2 * e)  # (settle into the cycle)
-                trial[e] = ctl.max_float(min(slab.step_rk4_timed(0.0, dt, 80)[0] / 80 for _ in range(2)))  # (80: whole cycles of each)
+                trial[e] = ctl.max_float(min(slab.step_rk4_timed(0.0, dt, span)[0] / span for _ in range(2)))
             keep = min(trial, key=lambda e: trial[e] * (1.0 if e == 8 else 1.01))  # (a longer period has to win by 1 %)
             slab.set_exchange_period(keep)
             period = {"steps": keep, "chosen_by": "rehearsal", "rehearsal_device_ms_per_step_max_over_ranks": {str(k): v for k, v in trial.items()}}

@@ -18,7 +18,9 @@ int fused_steps_supported(int precision, const SlabDesc &d, int want)
 #ifdef CRD_THREE_STEPS_GOLDBETER
 	three = three || (precision == CRD_PRECISION_F64 && kernel_model(d) == CRD_MODEL_GOLDBETER);
 #endif
-	if (want >= 3 && three && d.wrap && d.nyl >= 6 * kStepHalo) return 3;
+	// (single slabs; in fp32 -- a strip per wavefront -- the slabs of a multi-slab run too, inside their exchange cycles: the fp64 block strip
+	// measured nothing on a rank's share and keeps pairs there)
+	if (want >= 3 && three && (d.wrap || precision != CRD_PRECISION_F64) && d.nyl >= 6 * kStepHalo) return 3;
 	return (want >= 2 && fused_two_steps_supported(d)) ? 2 : 1;
 }
 

@@ -1499,8 +1499,10 @@ hipError_t launch_fused_t(const SlabDesc &d, const FusedCall &c, int row_begin, 
 		// a multi-slab cycle that reaches far into the ghost region is measured with the candidates of its own step count only)
 		const bool room_for_two = d.wrap || (row_begin >= -(kGhost - 2 * kStepHalo) && row_end <= d.nyl + (kGhost - 2 * kStepHalo));
 		const bool two_steps_ok = kCanTwoSteps && !c.embed && c.steps == 1 && d.nyl >= 4 * kStepHalo && room_for_two;  // (the caller steps pairs once the plan says so)
-		const bool three_steps_ok = two_steps_ok && kCanThreeSteps<Real, MODEL> && (kThreeStepCols<Real, MODEL> == 1 || cols2_ok) && d.nyl >= 6 * kStepHalo && d.wrap &&
-		                            !(sizeof(Real) == 4 && absorb12);  // (... or triples: single slabs; fp32 without absorbing rows on)
+		const bool room_for_three = d.wrap || (row_begin >= -(kGhost - 3 * kStepHalo) && row_end <= d.nyl + (kGhost - 3 * kStepHalo));
+		const bool three_steps_ok = two_steps_ok && kCanThreeSteps<Real, MODEL> && (kThreeStepCols<Real, MODEL> == 1 || cols2_ok) && d.nyl >= 6 * kStepHalo &&
+		                            (d.wrap || sizeof(Real) == 4) && room_for_three &&
+		                            !(sizeof(Real) == 4 && absorb12);  // (... or triples: single slabs, and in fp32 slabs of a run; fp32 without absorbing rows on)
 		float t_best[kCandidates];
 		bool live[kCandidates];
 		int reps = 3;

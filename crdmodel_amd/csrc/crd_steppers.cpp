@@ -151,7 +151,7 @@ int wait_for_halo(crd_ctx *c)
 
 // One launch of the cycle on every context of the call: `nsub` steps (1, or 2 with a two-steps-per-launch plan: the pair must not
 // straddle an exchange, q + nsub <= E) from cycle position q.  H = 4 nsub rows are consumed beyond the rows produced.
-int fused_launch_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, int nsub, bool timed_step, bool last_launch_of_call)
+int fused_launch_multi(crd_ctx *const *cs, int n, double t, double dt, int src, int dst, int q, int nsub, bool timed_step, bool last_launch_of_call, int max_nsub = 2)
 {
 	const int E = cycle_steps(cs[0]), G = cycle_ghost(cs[0]), B = cycle_band(cs[0]);
 	const int H = kStepHalo * nsub;
@@ -194,7 +194,7 @@ int fused_launch_multi(crd_ctx *const *cs, int n, double t, double dt, int src, 
 			// the interior sweep of the previous launch: the exchange gets this sweep as extra time to land.
 			const bool split = c->nyl >= 4 * B;
 			if (split) HIP_TRY(c, launch_fused_step(c->p.precision, c->desc, call, H, c->nyl - H, 0, 0, c->compute));
-			if (split && c->halo_slack >= 2 && !last_launch_of_call && q + nsub + 2 < E) {  // (whatever the next launch takes, one or two steps, it is not the cycle's last)
+			if (split && c->halo_slack >= 2 && !last_launch_of_call && q + nsub + max_nsub < E) {  // (whatever the next launch takes -- up to max_nsub steps --, it is not the cycle's last)
 				c->ghost_deferred = true;  // the wait and the rows that read ghost rows follow behind the NEXT launch's owned-only rows
 				c->deferred_t = t;
 				c->deferred_nsub = nsub;
@@ -409,7 +409,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		// Under RCCL that decision has to be the RING's, not this rank's: a rank that alone holds a new state (an upload on that
 		// rank only, a failed call) would prime its halo while its neighbours carry on, and the ring's send / receive sequences
 		// would no longer pair.  So the ranks reduce their positions first.  The reduction (and the host's wait for it) hides
-		// under the call's first step wherever that step involves no exchange of its own (q0 = 0 .. 6: the step is issued
+		// under the call's first step wherever that step involves no exchange of its own (q0 = 0 .. E - 4: the step is issued
 		// speculatively into the scratch planes and simply issued again, behind an exchange, if the ring turns out to disagree).
 		const bool ring = fused && n == 1 && lead->halo == CRD_HALO_RCCL;
 		bool agreement_pending = false;
@@ -419,7 +419,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			if (ring) {
 				if (int rc = begin_cycle_agreement(lead, q0)) return rc;
 				agreement_pending = true;
-				if (q0 < 0 || q0 >= E - 2) {  // nothing to issue ahead of the answer (the call's first launch may be the cycle's last, a pair included)
+				if (q0 < 0 || q0 >= E - 3) {  // nothing to issue ahead of the answer (the call's first launch may be the cycle's last: a pair, or -- fp32 -- a triple)
 					if (int rc = finish_cycle_agreement(lead, &q0)) return rc;
 					agreement_pending = false;
 				}
@@ -434,11 +434,20 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 		// Two steps per launch where the lead context's plan says so (measured, or pinned): pairs that do not straddle an exchange.
 		// Where the exchanges fall in the step sequence does not depend on the pairing, so the ranks of a ring / the threads of a group
 		// may pair differently (each by its own plan) and still meet at the same collectives.
-		bool pairs = fused && lead->plan.tuned && lead->plan.steps >= 2;  // (a three-step plan steps pairs inside an exchange cycle)
+		// Three where the three-step kernel takes slabs (fp32: a strip per wavefront; fp64's block strip measured nothing on a rank's
+		// share and keeps pairs: fused_steps_supported), by the same rule -- a triple never straddles an exchange either.
+		bool pairs = fused && lead->plan.tuned && lead->plan.steps >= 2;
 		for (int k = 0; k < n; k++) pairs = pairs && fused_two_steps_supported(cs[k]->desc);
+		bool triples = pairs && lead->plan.steps == 3;
+		for (int k = 0; k < n; k++) triples = triples && fused_steps_supported(cs[k]->p.precision, cs[k]->desc, 3) == 3;
 		for (int64_t s = 0; s < nsteps;) {
 			const int q = (int)((s + q0) % E);
-			const int nsub = (pairs && s + 2 <= nsteps && q + 2 <= E && pair_is_exact(lead, t0, s, dt)) ? 2 : 1;
+			const double t_s = t0 + (double)s * dt;
+			// (a launch is the cycle's first -- which waits for the halo -- or its last -- which sends the next --, never both: at E = 3 a
+			// triple from q = 0 would be; found by tests/long_oracle_sweep.py)
+			const int nsub = (triples && s + 3 <= nsteps && q + 3 <= E && (q > 0 || E > 3) && triple_is_exact(lead, t0, s, dt) && !triple_absorbs(lead, t_s, dt))
+			                     ? 3
+			                     : (pairs && s + 2 <= nsteps && q + 2 <= E && pair_is_exact(lead, t0, s, dt)) ? 2 : 1;
 			// time one launch of the dominant kernel mid-run (fused: a launch of the cycle that is one full-height sweep, i.e. neither
 			// the split first nor the split last one, nor the one that finishes a first whose ghost readers were deferred -- whatever
 			// the two launches take, one step or two)
@@ -449,7 +458,7 @@ int run_steps(crd_ctx *const *cs, int n, double t0, double dt, int64_t nsteps, i
 			const double t = t0 + (double)s * dt;
 			if (fused) {
 				const int dst = (cur == crd_ctx::Y) ? crd_ctx::SA : crd_ctx::Y;
-				if (int rc = fused_launch_multi(cs, n, t, dt, cur, dst, q, nsub, timed_step, s + nsub == nsteps)) return rc;
+				if (int rc = fused_launch_multi(cs, n, t, dt, cur, dst, q, nsub, timed_step, s + nsub == nsteps, triples ? 3 : 2)) return rc;
 				cur = dst;
 			} else if (int rc = staged_step_multi(cs, n, t, dt, timed_step)) {
 				return rc;

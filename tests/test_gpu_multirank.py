@@ -95,6 +95,34 @@ def plans(world, *per_rank):
     return [list(per_rank[k % len(per_rank)]) for k in range(world + 1)]
 
 
+def test_triples_inside_the_exchange_cycles_of_an_fp32_ring(gpu_device, standin, tmp_path):
+    """Round 6: fp32 slabs step THREE steps per launch inside their exchange cycles (a strip per wavefront, two columns per lane), each
+    rank by its own plan -- triples beside pairs beside single steps.  Two cases the soaks found when the ring first met triples:
+    (1) a call that starts E - 3 steps into a cycle begins with a triple that is the cycle's LAST launch, i.e. with an exchange --
+    it must not be issued ahead of the ring's agreement on the cycle position (here: an upload on one rank just before, so the ring
+    does disagree and starts afresh; the send / receive sequences stopped pairing: tools/soak_ring_processes.py, seed 70);
+    (2) at period 3 a triple from the cycle's start would be its first launch (which waits for the halo) and its last (which sends
+    the next) at once: it is stepped as a pair and a single step (tests/long_oracle_sweep.py, seed 71).  Bit-equal to the single slab."""
+    world = 3
+    ny = world * 131 + 2
+    spec = dict(model="fhn", surface="torus", nx=208, ny=ny, precision="f32", t_boundary=0.0, dt_factor=0.7, vary_beta=1)
+    dt = spec["dt_factor"] * crd.stable_dt(worker.problem(crd, spec))
+    spec["t_boundary"] = 30.4 * dt
+    three, two, one = (0, 0, 2, 1, 3), (0, 1, 2, 1, 2), (2, 1, 2, 0, 1)
+    spec["programme"] = [
+        ["plan", plans(world, three, three, one)], ["step", 5], ["scale_rows_of", 1, 1.0009765625], ["step", 9], ["snapshot"],   # period 8: q0 = 5 = E - 3
+        ["step", 13], ["scale_rows_of", 0, 0.9990234375], ["step", 4], ["snapshot"],
+        ["period", 3], ["step", 10], ["snapshot"], ["period", 4], ["step", 7], ["scale_rows_of", 2, 1.0009765625], ["step", 9], ["snapshot"],
+        ["period", 9], ["plan", plans(world, three, two, three)], ["slack", 2], ["step", 6], ["scale_rows_of", 1, 0.9990234375], ["step", 21], ["timed", 12],
+    ]
+    ring, _ = run_ring(standin, spec, world, tmp_path, shuffle_seed=3)
+    single, _ = run_single(spec, world)
+    assert len(ring) == len(single) == 5
+    for k, (a, b) in enumerate(zip(ring, single)):
+        assert np.array_equal(a, b), "snapshot %d: %.3e" % (k, rel(a, b))
+    assert np.abs(single[-1] - single[0]).max() > 1e-3
+
+
 @pytest.mark.parametrize("world,shuffle_seed", [(2, None), (3, None), (4, None), (2, 6), (5, 11)], ids=["2", "3", "4", "2-shuffled", "5-shuffled"])
 def test_fixed_steps_on_a_ring_of_processes(gpu_device, standin, tmp_path, world, shuffle_seed):
     """Exchange cycles carried across calls, periods 5 / 8 / 16, halo slack 2, launch plans that pair steps on some ranks only,
