@@ -451,9 +451,12 @@ typedef struct crd_launch_plan {
 	int32_t nontemporal_stores; /* 1: the new state is written with the non-temporal hint (it is not read again by the launch, and
 	                             * does not displace from L2 what neighbouring work items share) */
 	int32_t steps_per_launch; /* 1; 2: one launch advances the state by TWO RK4 steps (the state crosses memory once per two steps, for twice
-	                           * the pipeline registers and a 16-row / 16-column apron); crd_step_rk4 then issues pairs; 3 (FHN fp64 on a
-	                           * single slab; elsewhere taken as 2): THREE steps, a block's wavefronts running as one strip; triples, then
-	                           * a pair or a single step for what is left.  What crd_get_launch_plan reports is what a launch does. */
+	                           * the pipeline registers and a 16-row / 16-column apron); crd_step_rk4 then issues pairs; 3 (FHN: in fp64 on a
+	                           * single slab, a block's wavefronts running as one strip with one column per lane; in fp32 -- an even nx --
+	                           * with two columns per lane and a strip per wavefront, single slabs and the slabs of a run inside their
+	                           * exchange cycles; elsewhere taken as 2): THREE steps; triples, then a pair or a single step for what is
+	                           * left (fp32: also for triples any stage of which has the absorbing rows on).  What crd_get_launch_plan
+	                           * reports -- steps and columns -- is what a launch does. */
 	double ms_default, ms_chosen; /* measured times PER STEP: plain plan, chosen plan */
 } crd_launch_plan;
 int crd_set_autotune(crd_ctx *ctx, int on);
