@@ -443,6 +443,8 @@ def run_local(args, crd, ndev, emit):
             if args.launch_plan:
                 s.set_launch_plan(*[int(v) for v in args.launch_plan.split(",")])
             s.plan_launches()
+        if not args.exchange_period and all(s.launch_plan().get("steps_per_launch", 1) == 3 for s in grp.slabs):
+            grp.set_exchange_period(9)  # (plans that step triples inside the cycles -- fp32 -- want a period they divide: see the ring's rehearsal)
         preheat = {"ms_requested": args.preheat_ms, "steps": 0}
         if args.preheat_ms > 0:
             t0 = time.perf_counter()
