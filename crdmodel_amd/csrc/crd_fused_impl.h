@@ -885,7 +885,9 @@ __device__ __forceinline__ void fused_item_multi_step(const Slab<Real> &s, const
 		// Lockstep of the block's wavefronts: fp32 only.  With the rows coming through the rings, the fp64 pipelines run 1 - 5 % faster
 		// when their wavefronts drift (8192^2 FHN 0.2292 -> 0.2251 ms per step, 4096^2 0.0683 -> 0.0663, Goldbeter 4096^2 0.1212 -> 0.1148),
 		// the packed fp32 one 2 % slower (16384^2 0.4230 -> 0.4308; profiles/r05/two_step_memory_path_ab.txt).
-		if constexpr (sizeof(Real) == 4) __builtin_amdgcn_s_barrier();
+		// (round 6: ... and of the fp32 kernels only the two-step one: the three-step launch, bound by issue at two wavefronts per SIMD, runs
+		// 2 % faster without -- C5 0.3689 -> 0.3625 ms per step, 8192^2 0.0998 -> 0.0975; the two-step one 3 % slower, as before)
+		if constexpr (sizeof(Real) == 4 && STEPS == 2) __builtin_amdgcn_s_barrier();
 #endif
 		const int p = jbase + m;
 		Real b4[STEPS];  // b(j) of the rows stage 4 of each step works on, read before row p takes over the slot
