@@ -548,3 +548,32 @@ def test_multi_step_kernels_issue_their_stores_whatever_the_execution_mask():
     assert kernel_regs.exec_skipped_vmem(drained) == []
     unconditional = [ln for ln in skipped_store if "exec" not in ln]
     assert kernel_regs.exec_skipped_vmem(unconditional) == []
+    # The other contract with the compiler (round 6): the block-strip kernels issue the LDS reads of the neighbours' edge values in one asm
+    # block at the end of an iteration and wait for them in another at the start of the next; in between nothing may touch the registers
+    # the reads are in flight into -- the compiler believes them written and is free to copy them (an experiment that did the same for the
+    # ring reads got copies at the loop's back edge and results that changed from run to run).  Checked on the assembly of every build
+    # (kernel_regs.py: async_lds_read_hazards; the build stops on one), and here on the shape it must catch.
+    assert all(k.get("async_lds_read_hazards", 0) == 0 for k in doc["kernels"])
+    in_flight = """
+.LBB0_1:
+	;;#ASMSTART
+	s_waitcnt vmcnt(44)
+	ds_read_b64 v[10:11], v200 offset:0
+	s_waitcnt lgkmcnt(0)
+	;;#ASMEND
+	v_fma_f64 v[20:21], v[10:11], v[30:31], v[40:41]
+	;;#ASMSTART
+	s_waitcnt lgkmcnt(0)
+	s_barrier
+	ds_read_b128 v[46:49], v252 offset:0
+	;;#ASMEND
+	s_add_i32 s20, s20, 1
+	s_cmp_lt_i32 s20, s21
+	s_cbranch_scc1 .LBB0_1
+	s_endpgm
+""".splitlines()
+    assert kernel_regs.async_lds_read_hazards(in_flight) == []  # (nothing between the issue and the waiting block at the loop's head)
+    copied = list(in_flight)
+    copied.insert(14, "\tv_mov_b64_e32 v[60:61], v[48:49]")  # a copy of a register with a read in flight, in front of the back edge
+    hazards = kernel_regs.async_lds_read_hazards(copied)
+    assert len(hazards) == 1 and hazards[0][1] in (48, 49)

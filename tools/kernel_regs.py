@@ -84,6 +84,82 @@ def exec_skipped_vmem(body):
     return found
 
 
+def _regs_of(ln):
+    """The vector registers an instruction line mentions: {numbers}."""
+    out = set()
+    for a, b in re.findall(r"\bv\[(\d+):(\d+)\]", ln):
+        out.update(range(int(a), int(b) + 1))
+    out.update(int(n) for n in re.findall(r"\bv(\d+)\b", ln))
+    return out
+
+
+def async_lds_read_hazards(body):
+    """LDS reads an asm block issues WITHOUT waiting for them, whose destination registers something touches before an asm block's
+    `s_waitcnt lgkmcnt(0)`: [(line, register, offending instruction)].
+
+    The block-strip kernels issue the reads of the neighbours' edge values at the END of an iteration (crd_fused_impl.h: edge_exchange) and
+    wait for them at the start of the next (ring_read_with_edges), so that the LDS latency hides under the loop's turn-around.  The
+    compiler does not know that the first asm's outputs are not there yet: were it to copy or spill one of those registers between the
+    two asm blocks -- at the loop's back edge, say -- the copy would read a register whose data has not landed (round 6 met exactly that
+    when it tried the same for the ring reads: results changed from run to run).  Nothing in the language forbids it, so the build
+    checks the assembly: from each such read, along fall-through and taken branches, up to the waiting asm block, no instruction may
+    mention a destination register."""
+    n = len(body)
+    label_at = {}
+    for k, ln in enumerate(body):
+        m = re.match(r"^(\.LBB\d+_\d+):", ln)
+        if m:
+            label_at[m.group(1)] = k
+    in_asm = [False] * n
+    inside = False
+    for k, ln in enumerate(body):
+        if "#ASMSTART" in ln:
+            inside = True
+        in_asm[k] = inside
+        if "#ASMEND" in ln:
+            inside = False
+    found = []
+    for k, ln in enumerate(body):
+        t = ln.strip()
+        if not (in_asm[k] and t.startswith("ds_read")):
+            continue
+        # does this asm block wait for its own reads?
+        e = k
+        while e < n and "#ASMEND" not in body[e]:
+            e += 1
+        if any(re.match(r"\s*s_waitcnt\b.*lgkmcnt\(0\)", body[q]) for q in range(k + 1, e)):
+            continue
+        dst = _regs_of(t.split(",")[0])
+        seen, stack = set(), [e + 1]
+        while stack:
+            q = stack.pop()
+            steps = 0
+            while q < n and steps < 4000:
+                if q in seen:
+                    break
+                seen.add(q)
+                steps += 1
+                u = body[q].strip()
+                if in_asm[q] and re.match(r"s_waitcnt\b.*lgkmcnt\(0\)", u):
+                    break  # landed
+                if u and not u.startswith((";", ".")) and not u.endswith(":"):
+                    op = u.split()[0]
+                    if op == "s_endpgm":
+                        break
+                    hit = dst & _regs_of(u)
+                    # (the reads of one exchange sit in one asm block: its own other reads name other registers)
+                    if hit and not (in_asm[q] and op.startswith("ds_read") and not (dst & _regs_of(u.split(",")[0]))):
+                        found.append((k, min(hit), u))
+                        break
+                    mb = re.match(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", u)
+                    if mb and mb.group(1) in label_at:
+                        stack.append(label_at[mb.group(1)])
+                        if op == "s_branch":
+                            break
+                q += 1
+    return found
+
+
 def parse(text):
     """[{name (mangled), vgprs, sgprs, scratch, occupancy, lds, loop: {valu, salu, vmem, lds, other, total}}] for every kernel."""
     kernels = []
@@ -129,7 +205,8 @@ def parse(text):
             mix["total"] = sum(v for k_, v in mix.items() if k_ not in ("moves", "nops"))
             if best is None or mix["valu"] > best["valu"]:
                 best = mix
-        kernels.append({"mangled": name, "exec_skipped_vmem": len(exec_skipped_vmem(body)), "vgprs": meta.get("NumVgprs", 0), "sgprs": meta.get("TotalNumSgprs", meta.get("NumSgprs", 0)), "scratch": meta.get("ScratchSize", 0),
+        kernels.append({"mangled": name, "exec_skipped_vmem": len(exec_skipped_vmem(body)), "async_lds_read_hazards": len(async_lds_read_hazards(body)),
+                        "vgprs": meta.get("NumVgprs", 0), "sgprs": meta.get("TotalNumSgprs", meta.get("NumSgprs", 0)), "scratch": meta.get("ScratchSize", 0),
                         "occupancy": meta.get("Occupancy", 0), "lds": meta.get("LDSByteSize", 0), "loop": best or {"valu": 0, "salu": 0, "vmem": 0, "lds": 0, "other": 0, "moves": 0, "nops": 0, "total": 0}})
     for k, nm in zip(kernels, demangle([k["mangled"] for k in kernels])):
         k["name"] = nm
@@ -166,7 +243,7 @@ def main():
     for k in kernels:
         lp = k["loop"]
         print("%-64s %5d %5d %7d %4d %6d | %11d %5d %5d %4d %6d | %d" % (k["name"][:64], k["vgprs"], k["sgprs"], k["scratch"], k["occupancy"], k["lds"], lp["valu"], lp["salu"],
-                                                                          lp["vmem"], lp["lds"], lp["total"], k["exec_skipped_vmem"]))
+                                                                          lp["vmem"], lp["lds"], lp["total"], k["exec_skipped_vmem"]) + (" | async LDS read hazards: %d" % k["async_lds_read_hazards"] if k["async_lds_read_hazards"] else ""))
     rows = []
     for k in kernels:
         m = STEP_KERNEL.search(k["name"])
@@ -174,7 +251,8 @@ def main():
             real, model, absorb, embed, cols, nt, steps = m.groups()
             rows.append({"precision": "f64" if real == "double" else "f32", "model": int(model), "absorb": int(absorb == "true"), "embed": int(embed), "cols": int(cols),
                          "nt": int(nt == "true"), "steps": int(steps), "vgprs": k["vgprs"], "sgprs": k["sgprs"], "lds_bytes": k["lds"], "scratch_bytes": k["scratch"],
-                         "wavefronts_per_simd": k["occupancy"], "loop": k["loop"], "exec_skipped_vmem": k["exec_skipped_vmem"]})
+                         "wavefronts_per_simd": k["occupancy"], "loop": k["loop"], "exec_skipped_vmem": k["exec_skipped_vmem"],
+                         "async_lds_read_hazards": k["async_lds_read_hazards"]})
     if a.table:
         with open(a.table, "w") as f:
             f.write("// generated by tools/kernel_regs.py from the assembly of this build's step kernels -- do not edit\n")
@@ -191,6 +269,12 @@ def main():
 
 
     # The vmcnt contract of the multi-step pipelines (exec_skipped_vmem above): a build that breaks it does not go on.
+    for r in rows:
+        if r["async_lds_read_hazards"]:
+            sys.stderr.write("kernel_regs.py: %s model %d absorb %d cols %d nt %d steps %d: %d register(s) with LDS reads in flight touched before the asm block that waits "
+                             "for them\n" % (r["precision"], r["model"], r["absorb"], r["cols"], r["nt"], r["steps"], r["async_lds_read_hazards"]))
+    if any(r["async_lds_read_hazards"] for r in rows):
+        sys.exit(4)
     broken = [r for r in rows if r["steps"] >= 2 and r["exec_skipped_vmem"]]
     for r in broken:
         sys.stderr.write("kernel_regs.py: %s model %d absorb %d cols %d nt %d steps %d: %d vector-memory region(s) skipped on the execution mask -- the hand-counted "
